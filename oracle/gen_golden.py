@@ -1,0 +1,102 @@
+"""Mint tests/golden/*.pt by executing the reference's OWN modules (verbatim import,
+oracle/refshim.py) on CPU in fp32.  Run in the build container only:
+
+    python -m oracle.gen_golden
+
+Each fixture stores the reference OUTPUT plus the recipe (seed, shapes, config) needed
+to regenerate inputs / weights through oracle.detfill -- weights are never committed.
+The reference has no golden vectors of its own; these are it.
+"""
+import contextlib
+import io
+import os
+
+import torch
+
+from . import refshim
+from .detfill import det_fill, det_randn
+from .sdxl_unet import Attention
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+ATTN_CASES = {
+    # name: (B, L, C, heads, cross_dim, n_text, T_ip, scale)
+    "c640_t4": (2, 96, 640, 10, 2048, 77, 4, 0.7),
+    "c1280_t4": (1, 64, 1280, 20, 2048, 77, 4, 1.0),
+    "c1280_t16": (2, 32, 1280, 20, 2048, 77, 16, 0.5),
+    "c128_t32": (2, 160, 128, 2, 256, 77, 32, 1.0),
+}
+
+
+def attn_inputs(case, seed=11):
+    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    hs = det_randn((b, l, c), seed + 1)
+    ehs = det_randn((b, nt + t, cd), seed + 2)
+    return hs, ehs
+
+
+def make_attn(case, cross, seed=11):
+    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    a = Attention(c, h, 64, cross_attention_dim=cd if cross else None)
+    return det_fill(a, seed + 3, prefix="attn.")
+
+
+HA_CFG = dict(image_hidden_size=1280, text_context_dim=2048, inter_dim=2560, cross_heads=8,
+              reshape_blocks=8, cross_value_dim=64, scale=1.0, fusion_method="cross_attention")   # test.py:12-15,82-91
+RES_PLUSXL = dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, embedding_dim=1280,
+                  output_dim=2048, ff_mult=4)                                                     # ip_adapter.py:392-403
+RES_TEST = dict(dim=1024, depth=2, dim_head=64, heads=16, num_queries=8, embedding_dim=1280,
+                output_dim=1280, ff_mult=2, max_seq_len=257, apply_pos_emb=True,
+                num_latents_mean_pooled=4)                                                        # test_resampler.py:18-30
+
+
+@torch.no_grad()
+def main():
+    ref = refshim.load()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_grad_enabled(False)
+
+    # ---- attention processors (attention_processor.py:244-465) ----
+    for case, (b, l, c, h, cd, nt, t, scale) in ATTN_CASES.items():
+        hs, ehs = attn_inputs(case)
+        attn = make_attn(case, cross=True)
+        out = {}
+        for skip in (False, True):
+            p = ref.IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=skip)
+            det_fill(p, 17, prefix="proc.")
+            out[f"ip_skip{int(skip)}"] = p(attn, hs, encoder_hidden_states=ehs).clone()
+            if not skip:
+                out["attn_map"] = p.attn_map.clone()
+        # ControlNet processor == skip=True path (attention_processor.py:469-621)
+        out["cn"] = ref.CNAttnProcessor2_0(num_tokens=t)(attn, hs, encoder_hidden_states=ehs).clone()
+        sattn = make_attn(case, cross=False)
+        out["self"] = ref.AttnProcessor2_0()(sattn, hs).clone()
+        torch.save({"case": case, "cfg": ATTN_CASES[case], **out}, os.path.join(OUT, f"attn_{case}.pt"))
+        print(case, {k: tuple(v.shape) for k, v in out.items()})
+
+    # ---- HarmonyAttention + ImageProjModel (train.py:188-266, ip_adapter.py:28-48, :170-176) ----
+    with contextlib.redirect_stdout(io.StringIO()):      # reference prints in ctor/forward
+        ha = ref.HarmonyAttention(**HA_CFG)
+        det_fill(ha, 23, prefix="ha.")
+        text = det_randn((1, 77, 2048), 31)
+        img = det_randn((1, 1280), 32)
+        ha_out = ha(text, img)
+    proj = ref.ImageProjModel(cross_attention_dim=2048, clip_embeddings_dim=1280, clip_extra_context_tokens=4)
+    det_fill(proj, 29, prefix="proj.")
+    fused = img + ha_out
+    torch.save({"ha_out": ha_out, "tokens": proj(fused), "uncond_tokens": proj(torch.zeros_like(fused)),
+                "ha_cfg": HA_CFG}, os.path.join(OUT, "harmony_imageproj.pt"))
+    print("harmony", tuple(ha_out.shape))
+
+    # ---- Resampler (resampler.py:81-147) ----
+    for name, cfg, bsz in (("plusxl", RES_PLUSXL, 2), ("testcfg", RES_TEST, 2)):
+        r = ref.Resampler(**cfg)
+        det_fill(r, 37, prefix="res.")
+        x = det_randn((bsz, 257, cfg["embedding_dim"]), 41)
+        y = r(x)
+        torch.save({"out": y, "cfg": cfg, "batch": bsz}, os.path.join(OUT, f"resampler_{name}.pt"))
+        print("resampler", name, tuple(y.shape))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "refshim: needs /root/reference (build container only)")
+
+
+def rel_rms(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float(((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)))
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

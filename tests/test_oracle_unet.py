@@ -1,0 +1,94 @@
+"""CPU: structural pins of the restated SDXL UNet (diffusers is absent) and
+closed-form pins of the restated schedulers."""
+import numpy as np
+import torch
+
+from oracle.pipeline import denoise, install_ip_processors
+from oracle.schedulers import DDIMScheduler, EulerDiscreteScheduler
+from oracle.sdxl_unet import UNet2DConditionModel, sdxl_config, tiny_config
+from oracle.detfill import det_fill, det_randn
+from oracle import modules as om
+
+
+def test_sdxl_param_count_and_processor_schema():
+    with torch.device("meta"):
+        m = UNet2DConditionModel(sdxl_config())
+    assert sum(p.numel() for p in m.parameters()) == 2_567_463_684
+    ap = m.attn_processors
+    assert len(ap) == 140
+    assert sum(k.endswith("attn1.processor") for k in ap) == 70
+    active = [k for k in ap if "down_blocks.2.attentions.1" in k and k.endswith("attn2.processor")]
+    assert len(active) == 10
+    keys = list(ap)
+    # registration order down_blocks -> up_blocks -> mid_block; attn2 sits at the odd positions
+    assert keys[0].startswith("down_blocks.1.") and keys[-1].startswith("mid_block.")
+    assert all(keys[i].endswith("attn2.processor") for i in range(1, 140, 2))
+    sd = m.state_dict()
+    for k in ["conv_in.weight", "time_embedding.linear_1.weight", "add_embedding.linear_2.bias",
+              "down_blocks.0.resnets.1.time_emb_proj.weight", "down_blocks.0.downsamplers.0.conv.weight",
+              "down_blocks.1.resnets.0.conv_shortcut.weight", "down_blocks.2.attentions.1.proj_in.weight",
+              "down_blocks.2.attentions.1.transformer_blocks.9.attn2.to_out.0.bias",
+              "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "mid_block.resnets.1.norm2.weight", "up_blocks.0.upsamplers.0.conv.bias",
+              "up_blocks.1.attentions.2.transformer_blocks.1.ff.net.2.weight",
+              "up_blocks.2.resnets.2.conv_shortcut.bias", "conv_norm_out.weight", "conv_out.bias"]:
+        assert k in sd, k
+    assert sd["up_blocks.0.resnets.2.conv1.weight"].shape == (1280, 1920, 3, 3)
+    assert sd["up_blocks.2.resnets.0.conv1.weight"].shape == (320, 960, 3, 3)
+    assert sd["add_embedding.linear_1.weight"].shape == (1280, 2816)
+
+
+def test_ip_adapter_state_dict_keys_like_convert_bin():
+    """ModuleList(unet.attn_processors.values()) keys are '<odd idx>.to_k_ip.weight'
+    (ip_adapter/ip_adapter.py:153-154, convert_bin.py:21-40)."""
+    with torch.device("meta"):
+        m = UNet2DConditionModel(tiny_config())
+        install_ip_processors(m, num_tokens=4)
+        ml = torch.nn.ModuleList(m.attn_processors.values())
+    ks = list(ml.state_dict().keys())
+    n2 = sum(k.endswith("attn2.processor") for k in m.attn_processors)
+    assert len(ks) == 2 * n2
+    assert ks[0] == "1.to_k_ip.weight" and ks[1] == "1.to_v_ip.weight"
+
+
+def test_ddim_tables_and_identities():
+    s = DDIMScheduler()
+    s.set_timesteps(30)
+    ts = s.timesteps.tolist()
+    assert ts[0] == 958 and ts[1] == 925 and ts[-1] == 1 and len(ts) == 30
+    ac = s.alphas_cumprod
+    assert abs(float(ac[0]) - (1 - 0.00085)) < 1e-6 and abs(float(ac[-1]) - 0.0046596) < 2e-5
+    # exactness: if eps is the true noise, one step lands on sqrt(a')x0 + sqrt(1-a')eps
+    x0, eps = det_randn((1, 4, 8, 8), 1), det_randn((1, 4, 8, 8), 2)
+    t = 958
+    a = ac[t]
+    xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
+    ap = ac[t - 33]
+    assert torch.allclose(s.step(eps, t, xt)[0], ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=2e-5)
+
+
+def test_euler_tables():
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(30)
+    assert s.timesteps[0] == 958 and len(s.sigmas) == 31 and float(s.sigmas[-1]) == 0.0
+    assert abs(s.init_noise_sigma - float((s.sigmas[0] ** 2 + 1) ** 0.5)) < 1e-6
+    assert np.all(np.diff(s.sigmas.numpy()) < 0)
+
+
+def test_tiny_unet_denoise_runs_and_scale_gating():
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    with torch.no_grad():
+        unet = det_fill(UNet2DConditionModel(cfg), 5).eval()
+        procs = install_ip_processors(unet, num_tokens=4, scale=1.0)
+        for n, p in procs.items():
+            if isinstance(p, om.IPAttnProcessor2_0):
+                det_fill(p, 7, prefix=n)
+        lat = det_randn((1, 4, 16, 16), 3)
+        pe, ne = det_randn((1, 81, cfg.cross_attention_dim), 4), det_randn((1, 81, cfg.cross_attention_dim), 5)
+        po, no = det_randn((1, cfg.pooled_dim), 6), det_randn((1, cfg.pooled_dim), 7)
+        a = denoise(unet, DDIMScheduler(), lat, pe, ne, po, no, 128, 128, num_inference_steps=3)
+        b = denoise(unet, DDIMScheduler(), lat, pe, ne, po, no, 128, 128, num_inference_steps=3,
+                    control_guidance_end=0.0)       # IP scale gated off on every step
+        assert a.shape == lat.shape and torch.isfinite(a).all()
+        assert (a - b).abs().max() > 1e-4           # the IP branch matters
