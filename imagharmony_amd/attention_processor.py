@@ -1,0 +1,202 @@
+"""HIP attention processors behind the diffusers AttentionProcessor protocol.
+
+Drop-in replacements for the reference's ``AttnProcessor2_0`` / ``IPAttnProcessor2_0``
+(ip_adapter/attention_processor.py:244-332, :335-465): same constructor arguments, same
+attributes (``hidden_size, cross_attention_dim, scale, num_tokens, skip, to_k_ip, to_v_ip``),
+same state-dict keys, same ``__call__(attn, hidden_states, encoder_hidden_states=None,
+attention_mask=None, temb=None)`` contract (token-major ``[B, L, C]`` in and out), installed
+through ``unet.set_attn_processor`` exactly like the reference does (ip_adapter/ip_adapter.py:99-125).
+
+The arithmetic runs in libimh_hip.so: MFMA GEMMs for the projections and the flash /
+decoupled-cross-attention kernel of csrc/attention.hip.  There is no torch fallback.
+
+Two entry points per processor:
+  * ``__call__``  -- the eager plugin protocol (one call = one attention layer).
+  * ``emit``      -- records the same ops into a ``Ctx`` plan; used by the fused UNet forward, with the
+                     text / image-prompt K,V taken from a per-image cache (they do not depend on the
+                     denoise step; the reference recomputes them 30x).
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .ctx import Ctx
+
+HEAD_DIM = 64
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _w(attn_lin, ctx):
+    """weight of an nn.Linear-like holder in the compute dtype, contiguous, on the device"""
+    w = attn_lin.weight
+    if w.dtype != ctx.dtype or not w.is_contiguous() or w.device != ctx.device:
+        w = w.detach().to(device=ctx.device, dtype=ctx.dtype).contiguous()
+    return w.detach()
+
+
+def _b(attn_lin, ctx):
+    b = getattr(attn_lin, "bias", None)
+    if b is None:
+        return None
+    if b.dtype != ctx.dtype or b.device != ctx.device:
+        b = b.detach().to(device=ctx.device, dtype=ctx.dtype)
+    return b.detach().contiguous()
+
+
+def _packed_qk(attn, ctx):
+    """[Wq; Wk] stacked so Q and K of a self-attention layer come out of ONE GEMM; cached on the module."""
+    key = (attn.to_q.weight.data_ptr(), attn.to_k.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    cached = getattr(attn, "_imh_qk", None)
+    if cached is None or cached[0] != key:
+        w = torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0).to(device=ctx.device, dtype=ctx.dtype)
+        cached = (key, w.contiguous())
+        attn._imh_qk = cached
+    return cached[1]
+
+
+def _check_attn(attn, hidden_states, attention_mask):
+    if attention_mask is not None:
+        raise NotImplementedError("attention masks are not used on the SDXL path (attention_processor.py:283-287)")
+    if getattr(attn, "spatial_norm", None) is not None or getattr(attn, "group_norm", None) is not None \
+            or getattr(attn, "norm_cross", None):
+        raise NotImplementedError("spatial_norm / group_norm / norm_cross are dead branches for SDXL")
+    if hidden_states.ndim != 3:
+        raise NotImplementedError("4-D hidden states are a dead branch for SDXL (attention_processor.py:379-381)")
+
+
+class KVCache:
+    """Projected keys / values of one cross-attention layer in the layouts csrc/attention.hip wants:
+    K [B, Lk_pad, C] row-major, Vt [C, B*Lk_pad] (transposed, 16-key groups permuted)."""
+    __slots__ = ("k", "vt", "lk", "lk_pad", "k2", "vt2", "lk2", "lk2_pad")
+
+    def __init__(self):
+        self.k = self.vt = self.k2 = self.vt2 = None
+        self.lk = self.lk_pad = self.lk2 = self.lk2_pad = 0
+
+
+def project_kv(ctx, tokens, wk, wv):
+    """tokens [B, n, Cx] -> (K [B, n_pad, C], Vt [C, B*n_pad], n, n_pad).  Padding rows are zero."""
+    B, n, cx = tokens.shape
+    n_pad = _pad64(n)
+    x = torch.zeros(B, n_pad, cx, dtype=ctx.dtype, device=ctx.device)       # plumbing: zero-padded copy
+    x[:, :n] = tokens.to(device=ctx.device, dtype=ctx.dtype)
+    x2 = x.view(B * n_pad, cx)
+    k = ctx.gemm(x2, wk, descr="to_k")                                          # [B*n_pad, C]
+    vt = ctx.gemm(wv, x2, flags=L.GF_VT_PERM, descr="to_v^T")                   # [C, B*n_pad]
+    if ctx.record:
+        ctx.keep.append(x)
+    return k.view(B, n_pad, -1), vt, n, n_pad
+
+
+class AttnProcessor2_0(nn.Module):
+    """Self-attention (reference: attention_processor.py:244-332)."""
+
+    def __init__(self, hidden_size=None, cross_attention_dim=None):
+        super().__init__()
+
+    # -- recorded / fused path ------------------------------------------------------------
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None):
+        """x: [B*L, C] (already layer-normed).  Returns to_out(attention(x)) (+ residual).
+        lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
+        C_ = x.shape[1]
+        H = attn.heads
+        wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
+        qk = ctx.gemm(x, wqk, descr="self.to_qk")                               # [M, 2C]
+        vt = ctx.gemm(wv, x, flags=L.GF_VT_PERM, descr="self.to_v^T")           # [C, M]
+        ao = ctx.new(B * L_, C_)
+        ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
+                      HEAD_DIM ** -0.5, descr="self.attn")
+        out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
+                       descr="self.to_out")
+        ctx.free(qk); ctx.free(vt); ctx.free(ao)
+        return out
+
+    # -- eager plugin protocol ------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 *args, **kwargs):
+        _check_attn(attn, hidden_states, attention_mask)
+        if encoder_hidden_states is not None:
+            raise NotImplementedError("AttnProcessor2_0 with encoder_hidden_states: use IPAttnProcessor2_0(skip=True)")
+        ctx = Ctx(hidden_states.device, hidden_states.dtype)
+        B, L_, C_ = hidden_states.shape
+        Lp = _pad64(L_)
+        if Lp != L_:      # ragged sequence: zero-pad the rows, mask the padded keys (plumbing copy)
+            xp = torch.zeros(B, Lp, C_, dtype=hidden_states.dtype, device=hidden_states.device)
+            xp[:, :L_] = hidden_states
+        else:
+            xp = hidden_states.contiguous()
+        x = xp.view(B * Lp, C_)
+        res = x if attn.residual_connection else None
+        out = self.emit(ctx, attn, x, B, Lp, residual=res, lk=L_).view(B, Lp, C_)[:, :L_]
+        if attn.rescale_output_factor != 1.0:
+            out = out / attn.rescale_output_factor
+        return out
+
+
+class IPAttnProcessor2_0(nn.Module):
+    """Decoupled text + image-prompt cross-attention (reference: attention_processor.py:335-465)."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, scale=1.0, num_tokens=4, skip=False):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.scale = scale
+        self.num_tokens = num_tokens
+        self.skip = skip
+        self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+
+    def prepare_kv(self, ctx, attn, encoder_hidden_states):
+        """Step-invariant part: K/V of the text tokens (and of the image tokens if not skip).
+        The last ``num_tokens`` tokens are always sliced off, even when skip (attention_processor.py:402-406)."""
+        end = encoder_hidden_states.shape[1] - self.num_tokens
+        text, ip = encoder_hidden_states[:, :end], encoder_hidden_states[:, end:]
+        kv = KVCache()
+        kv.k, kv.vt, kv.lk, kv.lk_pad = project_kv(ctx, text, _w(attn.to_k, ctx), _w(attn.to_v, ctx))
+        if not self.skip:
+            kv.k2, kv.vt2, kv.lk2, kv.lk2_pad = project_kv(ctx, ip, _w(self.to_k_ip, ctx), _w(self.to_v_ip, ctx))
+        return kv
+
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None):
+        C_ = x.shape[1]
+        H = attn.heads
+        q = ctx.gemm(x, _w(attn.to_q, ctx), descr="cross.to_q")
+        ao = ctx.new(B * L_, C_)
+        if kv.k2 is not None:
+            ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
+                          k2=kv.k2, vt2=kv.vt2, Lk2=kv.lk2, Lk2_pad=kv.lk2_pad, ldk2=C_, ldvt2=B * kv.lk2_pad,
+                          scale2=float(self.scale), scale2_tab=scale_tab, step=step if scale_tab is not None else None,
+                          descr="cross.attn+ip")
+        else:
+            ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
+                          descr="cross.attn")
+        out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
+                       descr="cross.to_out")
+        ctx.free(q); ctx.free(ao)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        _check_attn(attn, hidden_states, attention_mask)
+        if encoder_hidden_states is None:
+            raise NotImplementedError("IPAttnProcessor2_0 is installed on cross-attention layers only "
+                                      "(ip_adapter/ip_adapter.py:113-123)")
+        ctx = Ctx(hidden_states.device, hidden_states.dtype)
+        B, L_, C_ = hidden_states.shape
+        x = hidden_states.contiguous().view(B * L_, C_)
+        kv = self.prepare_kv(ctx, attn, encoder_hidden_states)
+        res = x if attn.residual_connection else None
+        out = self.emit(ctx, attn, x, B, L_, residual=res, kv=kv).view(B, L_, C_)
+        if attn.rescale_output_factor != 1.0:
+            out = out / attn.rescale_output_factor
+        return out
+
+
+# the reference aliases these names when torch >= 2 (ip_adapter/ip_adapter.py:13-24); the isinstance()
+# checks in set_scale (ip_adapter.py:181, custom_pipelines.py:19,320) go through them
+AttnProcessor = AttnProcessor2_0
+IPAttnProcessor = IPAttnProcessor2_0

@@ -1,0 +1,254 @@
+// C ABI of libimh_hip.so (include/imh.h): argument validation, dispatch to the kernel
+// launchers, and the plan executor (recorded launch sequences + hipGraph capture).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/imh.h"
+#include "imh_common.h"
+#include "imh_kernels.h"
+
+namespace imh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return IMH_ERR_LAUNCH;
+    }
+    return IMH_OK;
+}
+
+static int do_gemm(const imh_gemm_args* a, hipStream_t s) {
+    if (!a || !a->X || !a->W || !a->Y) { set_error("gemm: null pointer argument"); return IMH_ERR_ARG; }
+    GemmParams p;
+    p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
+    p.residual = a->residual;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
+    p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
+    p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.stride = a->stride; p.up = a->up;
+    int bm = a->bm, bn = a->bn;
+    if (bm <= 0 || bn <= 0 || p.splits <= 0) {
+        int hb, hn, hs;
+        gemm_pick_config(p.M, p.N, p.K, &hb, &hn, &hs);
+        if (bm <= 0) bm = hb;
+        if (bn <= 0) bn = hn;
+        if (p.splits <= 0) p.splits = p.partial ? hs : 1;
+    }
+    if ((p.flags & IMH_GF_VT_PERM) && p.splits == 1) bn = 128;   // the permutation lives in 16-column groups
+    if (a->conv) {
+        if (p.stride != 1 && p.stride != 2) { set_error("conv3x3: stride must be 1 or 2"); return IMH_ERR_ARG; }
+        if (p.up != 0 && p.up != 1) { set_error("conv3x3: up must be 0 or 1"); return IMH_ERR_ARG; }
+        const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+        if (p.Ho != (Hv + 2 - 3) / p.stride + 1 || p.Wo != (Wv + 2 - 3) / p.stride + 1) {
+            set_error("conv3x3: output size %dx%d inconsistent with input %dx%d up=%d stride=%d", p.Ho, p.Wo, p.H, p.Wd, p.up, p.stride);
+            return IMH_ERR_SHAPE;
+        }
+        if (p.M % (p.Ho * p.Wo) != 0) { set_error("conv3x3: M must be B*Ho*Wo"); return IMH_ERR_SHAPE; }
+    }
+    return gemm_launch(p, a->dtype, a->conv, bm, bn, s);
+}
+
+static int do_attn(const imh_attn_args* a, hipStream_t s) {
+    if (!a || !a->Q || !a->K || !a->Vt || !a->O) { set_error("attention: null pointer argument"); return IMH_ERR_ARG; }
+    if ((a->K2 == nullptr) != (a->Vt2 == nullptr)) { set_error("attention: K2 and Vt2 must come together"); return IMH_ERR_ARG; }
+    AttnParams p;
+    p.Q = a->Q; p.K = a->K; p.Vt = a->Vt; p.K2 = a->K2; p.Vt2 = a->Vt2; p.O = a->O;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.Lk_pad = a->Lk_pad; p.Lk2 = a->Lk2; p.Lk2_pad = a->Lk2_pad;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldk2 = a->ldk2; p.ldvt2 = a->ldvt2; p.ldo = a->ldo;
+    p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step;
+    return attention_launch(p, a->dtype, s);
+}
+
+static NormParams to_norm(const imh_norm_args* a) {
+    NormParams p;
+    p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.partial = a->partial;
+    p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.rows = a->rows; p.eps = a->eps; p.silu = a->silu;
+    return p;
+}
+
+static int do_ew(int op, const imh_ew_args* a, hipStream_t s) {
+    if (!a || !a->y) { set_error("elementwise: null pointer argument"); return IMH_ERR_ARG; }
+    EwParams p;
+    p.a = a->a; p.b = a->b; p.y = a->y; p.w = a->w; p.bias = a->bias; p.tab = a->tab; p.step = a->step; p.n = a->n;
+    p.i0 = a->i0; p.i1 = a->i1; p.i2 = a->i2; p.i3 = a->i3; p.i4 = a->i4; p.i5 = a->i5;
+    p.f0 = a->f0; p.f1 = a->f1; p.f2 = a->f2; p.f3 = a->f3;
+    return ew_launch(op, p, a->dtype, s);
+}
+
+}  // namespace imh
+
+using namespace imh;
+
+struct imh_op {
+    int kind;
+    int ew_op;
+    int tag;
+    union {
+        imh_gemm_args gemm;
+        imh_attn_args attn;
+        imh_norm_args norm;
+        imh_ew_args ew;
+    } u;
+};
+
+struct imh_plan {
+    std::vector<imh_op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+static int run_op(const imh_op& o, hipStream_t s) {
+    switch (o.kind) {
+        case IMH_OP_GEMM: return do_gemm(&o.u.gemm, s);
+        case IMH_OP_ATTN: return do_attn(&o.u.attn, s);
+        case IMH_OP_GROUPNORM: {
+            if (!o.u.norm.x || !o.u.norm.y) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }
+            return groupnorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
+        }
+        case IMH_OP_LAYERNORM: {
+            if (!o.u.norm.x || !o.u.norm.y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
+            return layernorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
+        }
+        case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
+    }
+    set_error("plan: unknown op kind %d", o.kind);
+    return IMH_ERR_ARG;
+}
+
+static void drop_graph(imh_plan* p) {
+    if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+}
+
+static size_t args_size(int kind) {
+    switch (kind) {
+        case IMH_OP_GEMM: return sizeof(imh_gemm_args);
+        case IMH_OP_ATTN: return sizeof(imh_attn_args);
+        case IMH_OP_GROUPNORM:
+        case IMH_OP_LAYERNORM: return sizeof(imh_norm_args);
+        case IMH_OP_EW: return sizeof(imh_ew_args);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int imh_abi_version(void) { return IMH_ABI_VERSION; }
+const char* imh_last_error(void) { return g_err; }
+
+int imh_gemm(const imh_gemm_args* a, void* stream) { return do_gemm(a, (hipStream_t)stream); }
+int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
+    if (!bm || !bn || !splits) { set_error("pick_config: null output"); return IMH_ERR_ARG; }
+    gemm_pick_config(M, N, K, bm, bn, splits);
+    return IMH_OK;
+}
+size_t imh_gemm_workspace_bytes(int M, int N, int splits) { return gemm_workspace_bytes(M, N, splits); }
+
+int imh_attention(const imh_attn_args* a, void* stream) { return do_attn(a, (hipStream_t)stream); }
+
+int imh_groupnorm(const imh_norm_args* a, void* stream) {
+    if (!a || !a->x || !a->y) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }
+    return groupnorm_launch(to_norm(a), a->dtype, (hipStream_t)stream);
+}
+size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups) { return groupnorm_workspace_bytes(B, HW, C, groups); }
+int imh_layernorm(const imh_norm_args* a, void* stream) {
+    if (!a || !a->x || !a->y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
+    return layernorm_launch(to_norm(a), a->dtype, (hipStream_t)stream);
+}
+
+int imh_elementwise(int op, const imh_ew_args* a, void* stream) { return do_ew(op, a, (hipStream_t)stream); }
+
+imh_plan* imh_plan_create(void) { return new (std::nothrow) imh_plan(); }
+void imh_plan_destroy(imh_plan* p) {
+    if (!p) return;
+    drop_graph(p);
+    delete p;
+}
+int imh_plan_add(imh_plan* p, int kind, const void* args, int ew_op, int tag) {
+    if (!p || !args) { set_error("plan_add: null argument"); return IMH_ERR_ARG; }
+    const size_t sz = args_size(kind);
+    if (!sz) { set_error("plan_add: unknown kind %d", kind); return IMH_ERR_ARG; }
+    imh_op o;
+    memset(&o, 0, sizeof(o));
+    o.kind = kind; o.ew_op = ew_op; o.tag = tag;
+    memcpy(&o.u, args, sz);
+    p->ops.push_back(o);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+int imh_plan_size(const imh_plan* p) { return p ? (int)p->ops.size() : 0; }
+int imh_plan_update(imh_plan* p, int index, const void* args) {
+    if (!p || !args || index < 0 || index >= (int)p->ops.size()) { set_error("plan_update: bad index"); return IMH_ERR_ARG; }
+    memcpy(&p->ops[index].u, args, args_size(p->ops[index].kind));
+    drop_graph(p);
+    return IMH_OK;
+}
+int imh_plan_run_range(imh_plan* p, int first, int last, void* stream) {
+    if (!p || first < 0 || last > (int)p->ops.size() || first > last) { set_error("plan_run: bad range"); return IMH_ERR_ARG; }
+    for (int i = first; i < last; ++i) {
+        int rc = run_op(p->ops[i], (hipStream_t)stream);
+        if (rc != IMH_OK) return rc;
+    }
+    return IMH_OK;
+}
+int imh_plan_run(imh_plan* p, void* stream) { return imh_plan_run_range(p, 0, p ? (int)p->ops.size() : 0, stream); }
+
+int imh_plan_capture(imh_plan* p, void* stream) {
+    if (!p) { set_error("plan_capture: null plan"); return IMH_ERR_ARG; }
+    drop_graph(p);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("plan_capture: begin: %s", hipGetErrorString(e)); return IMH_ERR_LAUNCH; }
+    int rc = imh_plan_run(p, stream);
+    e = hipStreamEndCapture(s, &p->graph);
+    if (rc != IMH_OK) { drop_graph(p); return rc; }
+    if (e != hipSuccess) { set_error("plan_capture: end: %s", hipGetErrorString(e)); drop_graph(p); return IMH_ERR_LAUNCH; }
+    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { set_error("plan_capture: instantiate: %s", hipGetErrorString(e)); drop_graph(p); return IMH_ERR_LAUNCH; }
+    return IMH_OK;
+}
+int imh_plan_replay(imh_plan* p, void* stream) {
+    if (!p || !p->exec) { set_error("plan_replay: plan not captured"); return IMH_ERR_ARG; }
+    hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("plan_replay: %s", hipGetErrorString(e)); return IMH_ERR_LAUNCH; }
+    return IMH_OK;
+}
+int imh_plan_time_ops(imh_plan* p, void* stream, float* ms, int n) {
+    if (!p || !ms || n < (int)p->ops.size()) { set_error("plan_time_ops: bad arguments"); return IMH_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    const int cnt = (int)p->ops.size();
+    std::vector<hipEvent_t> ev(cnt + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    int rc = IMH_OK;
+    hipEventRecord(ev[0], s);
+    for (int i = 0; i < cnt && rc == IMH_OK; ++i) {
+        rc = run_op(p->ops[i], s);
+        hipEventRecord(ev[i + 1], s);
+    }
+    hipStreamSynchronize(s);
+    if (rc == IMH_OK)
+        for (int i = 0; i < cnt; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+int imh_plan_get_tag(const imh_plan* p, int index) {
+    return (p && index >= 0 && index < (int)p->ops.size()) ? p->ops[index].tag : -1;
+}
+int imh_plan_get_kind(const imh_plan* p, int index) {
+    return (p && index >= 0 && index < (int)p->ops.size()) ? p->ops[index].kind : -1;
+}
+
+}  // extern "C"

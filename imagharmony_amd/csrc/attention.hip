@@ -1,0 +1,208 @@
+// Flash attention for gfx950, head_dim 64: the self-attention of AttnProcessor2_0
+// (ip_adapter/attention_processor.py:305-316) and the decoupled text + image-prompt
+// cross-attention of IPAttnProcessor2_0 (:416-450):
+//
+//     O = softmax(Q K^T / 8) V  [ + scale2 * softmax(Q K2^T / 8) V2 ]
+//
+// Structure (cdna_hip_programming.md Appendix B "8-warp 32x32 ladder", simplified):
+// 4 waves x 32 query rows per workgroup, KV tiles of 64 keys double-buffered in LDS by
+// global_load_lds (XOR-swizzled on the source side), swapped QK^T (S^T = K Q^T with
+// v_mfma_f32_32x32x16) so that every lane owns one query row: the online softmax is
+// in-register (one cross-half shuffle per tile), P never touches LDS, and O^T = V^T P^T
+// accumulates with the query as the lane-local column.  V arrives TRANSPOSED with keys
+// permuted inside 16-groups (imh_layout.h vt_perm16) -- the producing GEMM writes it that
+// way -- so the V^T operand is one ds_read_b128 and no LDS transpose is needed.
+// The two softmaxes of the IP branch run as two passes over different key sets inside the
+// same kernel; Q stays in registers, the combination happens before the single store.
+// Roofline: self-attention MFMA-bound; cross-attention (77+T keys) HBM-bound on Q/O.
+#include "imh_common.h"
+#include "imh_kernels.h"
+
+namespace imh {
+
+constexpr int ATT_KV = 64;              // keys per LDS tile
+constexpr int ATT_TILE_BYTES = 64 * 128;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * ATT_TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31;
+    const int hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + l32;
+    const int qc = min(q, p.Lq - 1);
+
+    // Q^T B-operand: lane (col q, half hi) holds d = sd*16 + hi*8 + 0..7
+    v8 qf[4];
+    {
+        const T* qp = (const T*)p.Q + ((size_t)b * p.Lq + qc) * p.ldq + h * 64 + hi * 8;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qp + sd * 16);
+    }
+
+    const float c = p.scale * LOG2E;
+
+
+    f32x16 fin[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[dt][r] = 0.f;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const T* Kp = (const T*)(pass == 0 ? p.K : p.K2);
+        const T* Vp = (const T*)(pass == 0 ? p.Vt : p.Vt2);
+        if (pass == 1 && Kp == nullptr) break;
+        const int Lk = pass == 0 ? p.Lk : p.Lk2;
+        const int Lkp = pass == 0 ? p.Lk_pad : p.Lk2_pad;
+        const int ldk = pass == 0 ? p.ldk : p.ldk2;
+        const int ldvt = pass == 0 ? p.ldvt : p.ldvt2;
+        const float wgt = pass == 0 ? 1.0f : (p.scale2_tab ? p.scale2_tab[*p.step] : p.scale2);
+        const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+
+        auto stage = [&](int buf, int tile) {
+            unsigned char* ks = smem + buf * 2 * ATT_TILE_BYTES;
+            unsigned char* vs = ks + ATT_TILE_BYTES;
+            const int kbase = tile * ATT_KV;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = stage_row(i, wave, lane);
+                const int ch = stage_chunk_x(row, lane);
+                const T* ksrc = Kp + ((size_t)b * Lkp + kbase + row) * ldk + h * 64 + ch * 8;
+                glds16(ksrc, ks + stage_lds_off(i, wave));
+                const T* vsrc = Vp + ((size_t)h * 64 + row) * ldvt + (size_t)b * Lkp + kbase + ch * 8;
+                glds16(vsrc, vs + stage_lds_off(i, wave));
+            }
+        };
+
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = NEG_BIG, l_run = 0.f;
+
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+            const unsigned char* ks = smem + cur * 2 * ATT_TILE_BYTES;
+            const unsigned char* vs = ks + ATT_TILE_BYTES;
+            const int kbase = t * ATT_KV;
+            const bool second = kbase + 32 < Lk;   // wave-uniform: is the 2nd 32-key sub-tile live?
+
+            // ---- S^T = K Q^T ----
+            f32x16 st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+                if (kt == 1 && !second) continue;
+#pragma unroll
+                for (int sd = 0; sd < 4; ++sd) {
+                    v8 kf = *(const v8*)(ks + att_k_off(lane, kt, sd));
+                    st[kt] = mfma32(kf, qf[sd], st[kt]);
+                }
+            }
+            // ---- scale, mask, online softmax (lane-local row; one cross-half exchange) ----
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kt * 32 + st_key(r, hi);
+                    float s = st[kt][r] * c;
+                    s = key < Lk ? s : NEG_BIG;
+                    st[kt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.f;
+            v8 pf[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                    psum += pv;
+                    pf[kt][r >> 3][r & 7] = from_f32<T>(pv);
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            // ---- O^T += V^T P^T ----
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 1 && !second) continue;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        v8 vf = *(const v8*)(vs + att_v_off(lane, dt, kt, s));
+                        o[dt] = mfma32(vf, pf[kt][s], o[dt]);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = wgt / l_tot;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[dt][r] += o[dt][r] * inv;
+    }
+
+    // ---- store: lane (q, hi) owns d = dt*32 + 8*(r>>2) + 4*hi + (r&3) ----
+    if (q < p.Lq) {
+        T* op = (T*)p.O + ((size_t)b * p.Lq + q) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                v4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(fin[dt][rg * 4 + e]);
+                *(v4*)(op + dt * 32 + rg * 8) = o4;
+            }
+    }
+}
+
+int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
+    if (p.Lk <= 0 || p.Lk_pad % ATT_KV != 0 || p.Lk_pad < p.Lk) {
+        set_error("attention: Lk=%d Lk_pad=%d (pad must be a multiple of 64 and >= Lk)", p.Lk, p.Lk_pad);
+        return IMH_ERR_SHAPE;
+    }
+    if (p.K2 && (p.Lk2 <= 0 || p.Lk2_pad % ATT_KV != 0 || p.Lk2_pad < p.Lk2)) {
+        set_error("attention: Lk2=%d Lk2_pad=%d invalid", p.Lk2, p.Lk2_pad);
+        return IMH_ERR_SHAPE;
+    }
+    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 3) || (p.K2 && ((p.ldk2 & 7) || (p.ldvt2 & 7)))) {
+        set_error("attention: leading dimensions must be multiples of 8 elements");
+        return IMH_ERR_SHAPE;
+    }
+    if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("attention: empty problem"); return IMH_ERR_SHAPE; }
+    dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, stream, p);
+    else if (dtype == IMH_DT_F16) hipLaunchKernelGGL((attn_kernel<f16_t>), grid, dim3(256), 0, stream, p);
+    else { set_error("attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    return check_launch("attn_kernel");
+}
+
+}  // namespace imh

@@ -1,0 +1,219 @@
+// Small memory-/latency-bound kernels around the UNet forward and the denoise loop, gfx950.
+//   EW_TIMESTEP   diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0)      
+//   EW_SILU       SiLU on the time embedding before time_emb_proj               (App. A ResnetBlock2D)
+//   EW_CONCAT     channel concat of NHWC tensors (up-block skip connections)    (App. A.6)
+//   EW_CONV_IN    conv_in 3x3 (4 -> C0) reading NCHW fp32 latents, fusing CFG duplication
+//                 (custom_pipelines.py:332) and scale_model_input (:334); writes NHWC
+//   EW_CFG_STEP   CFG combine (custom_pipelines.py:348-350) + linear scheduler update
+//                 x' = cx*x + ce*eps (DDIM eta=0 / Euler), noise pred read
+//                 NHWC, latents kept NCHW fp32 (custom_pipelines.py:357)
+//   EW_CAST_F32   T -> fp32 copy (debug / host-side plumbing)
+//   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
+// Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
+// indexed by *step instead of the immediate f0..f2 fields.
+#include "imh_common.h"
+#include "imh_kernels.h"
+
+namespace imh {
+
+enum : int { EW_TIMESTEP = 0, EW_SILU = 1, EW_CONCAT = 2, EW_CONV_IN = 3, EW_CFG_STEP = 4, EW_CAST_F32 = 5,
+             EW_ADD = 6, EW_STEP_SET = 7 };
+
+// a: fp32 values [n_vals]; y: T [n_vals, dim]; cos first, then sin.
+template <typename T>
+__global__ void timestep_kernel(const EwParams p) {
+    const int dim = p.i0, half = dim >> 1;
+    const long long total = p.n * half;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / half), j = (int)(i % half);
+        const float t = p.step ? ((const float*)p.a)[*p.step] : ((const float*)p.a)[v];
+        const float f = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
+        const float a = t * f;
+        T* y = (T*)p.y + (size_t)v * dim;
+        y[j] = from_f32<T>(cosf(a));
+        y[half + j] = from_f32<T>(sinf(a));
+    }
+}
+
+template <typename T>
+__global__ void silu_kernel(const EwParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const long long nv = p.n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        v8 v = ((const v8*)p.a)[i], o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(silu_f(to_f32(v[e])));
+        ((v8*)p.y)[i] = o;
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const EwParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const long long nv = p.n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        v8 u = ((const v8*)p.a)[i], v = ((const v8*)p.b)[i], o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(to_f32(u[e]) + to_f32(v[e]));
+        ((v8*)p.y)[i] = o;
+    }
+}
+
+// y[pix, 0:C1] = a[pix], y[pix, C1:C1+C2] = b[pix]   (n = pixels, C1 = i0, C2 = i1; multiples of 8)
+template <typename T>
+__global__ void concat_kernel(const EwParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const int c1 = p.i0 >> 3, c2 = p.i1 >> 3, ct = c1 + c2;
+    const long long total = p.n * ct;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / ct;
+        const int c = (int)(i - pix * ct);
+        v8 v = c < c1 ? ((const v8*)p.a)[pix * c1 + c] : ((const v8*)p.b)[pix * c2 + (c - c1)];
+        ((v8*)p.y)[i] = v;
+    }
+}
+
+// conv_in: a = latents fp32 NCHW [S, 4, H, W]; w = weights T [C0][4][3][3]; bias T [C0];
+// y = NHWC T [Bout, H, W, C0] with Bout = i4 (batch b reads latent b % S: CFG duplication).
+// i0 = S, i1 = H, i2 = W, i3 = C0, f0 = input scale.  One thread = one pixel x 8 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_kernel(const EwParams p) {
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ float wl[];   // [36][C0] transposed weights, then [C0] bias
+    const int S = p.i0, H = p.i1, W = p.i2, C0 = p.i3, Bout = p.i4;
+    const T* w = (const T*)p.w;
+    for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
+        const int co = i / 36, k = i % 36;
+        wl[k * C0 + co] = to_f32(w[i]);
+    }
+    for (int i = threadIdx.x; i < C0; i += blockDim.x) wl[36 * C0 + i] = p.bias ? to_f32(((const T*)p.bias)[i]) : 0.f;
+    __syncthreads();
+    const int cg = C0 >> 3;
+    const float in_scale = p.tab ? p.tab[*p.step] : p.f0;
+    const long long total = (long long)Bout * H * W * cg;
+    const float* lat = (const float*)p.a;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        const long long pix = i / cg;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int b = (int)(pix / ((long long)W * H));
+        const float* src = lat + (size_t)(b % S) * 4 * H * W;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = wl[36 * C0 + c8 * 8 + e];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = y + ky - 1, ix = x + kx - 1;
+                    float v = 0.f;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = src[((size_t)ci * H + iy) * W + ix] * in_scale;
+                    // the model sees the latent rounded to the compute dtype (pipeline casts latents)
+                    v = to_f32(from_f32<T>(v));
+                    const float* wr = wl + (ci * 9 + ky * 3 + kx) * C0 + c8 * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
+                }
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
+        ((v8*)p.y)[i] = o;
+    }
+}
+
+// a = noise prediction NHWC T [2S or S, HW, 4] (i3 = 1: CFG, batch order [uncond | cond]);
+// y = latents fp32 NCHW [S, 4, HW] updated in place: x' = f0*x + f1*eps, eps = u + f2*(c-u).
+// i0 = S, i1 = HW.  b (optional) = fp32 copy of eps out (NCHW), for tests.
+template <typename T>
+__global__ void cfg_step_kernel(const EwParams p) {
+    const int S = p.i0, HW = p.i1;
+    const long long total = (long long)S * HW * 4;
+    const T* np_ = (const T*)p.a;
+    float* lat = (float*)p.y;
+    const float cx = p.tab ? p.tab[*p.step * 2] : p.f0;
+    const float ce = p.tab ? p.tab[*p.step * 2 + 1] : p.f1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const int ch = (int)((i / HW) % 4);
+        const int s = (int)(i / ((long long)HW * 4));
+        float eps;
+        if (p.i3) {
+            const float u = to_f32(np_[((size_t)s * HW + pix) * 4 + ch]);
+            const float c = to_f32(np_[((size_t)(S + s) * HW + pix) * 4 + ch]);
+            eps = u + p.f2 * (c - u);
+        } else {
+            eps = to_f32(np_[((size_t)s * HW + pix) * 4 + ch]);
+        }
+        if (p.b) ((float*)p.b)[i] = eps;
+        lat[i] = cx * lat[i] + ce * eps;
+    }
+}
+
+__global__ void step_set_kernel(int* step, int value, int set) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step = set ? value : *step + 1;
+}
+
+template <typename T>
+__global__ void cast_f32_kernel(const EwParams p) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x)
+        ((float*)p.y)[i] = to_f32(((const T*)p.a)[i]);
+}
+
+static inline int grid_for(long long work, int threads) {
+    long long g = (work + threads - 1) / threads;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+template <typename T>
+static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
+    switch (op) {
+        case EW_TIMESTEP:
+            if (p.i0 <= 0 || (p.i0 & 1)) { set_error("timestep: dim must be even"); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((timestep_kernel<T>), dim3(grid_for(p.n * (p.i0 >> 1), 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_SILU:
+            if (p.n & 7) { set_error("silu: n must be a multiple of 8"); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((silu_kernel<T>), dim3(grid_for(p.n >> 3, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_ADD:
+            if (p.n & 7) { set_error("add: n must be a multiple of 8"); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(p.n >> 3, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_CONCAT:
+            if ((p.i0 & 7) || (p.i1 & 7)) { set_error("concat: channel counts must be multiples of 8"); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((concat_kernel<T>), dim3(grid_for(p.n * ((p.i0 + p.i1) >> 3), 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_CONV_IN: {
+            if (p.i3 & 7) { set_error("conv_in: C0 must be a multiple of 8"); return IMH_ERR_SHAPE; }
+            const size_t lds = (size_t)(37 * p.i3) * sizeof(float);
+            const long long work = (long long)p.i4 * p.i1 * p.i2 * (p.i3 >> 3);
+            hipLaunchKernelGGL((conv_in_kernel<T>), dim3(grid_for(work, 256 * 4)), dim3(256), lds, stream, p);
+            break;
+        }
+        case EW_CFG_STEP:
+            hipLaunchKernelGGL((cfg_step_kernel<T>), dim3(grid_for((long long)p.i0 * p.i1 * 4, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_CAST_F32:
+            hipLaunchKernelGGL((cast_f32_kernel<T>), dim3(grid_for(p.n, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_STEP_SET:
+            hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(64), 0, stream, (int*)p.y, p.i0, p.i1);
+            break;
+        default:
+            set_error("elementwise: unknown op %d", op);
+            return IMH_ERR_ARG;
+    }
+    return check_launch("elementwise");
+}
+
+int ew_launch(int op, const EwParams& p, int dtype, hipStream_t stream) {
+    if (dtype == IMH_DT_BF16) return ew_typed<bf16_t>(op, p, stream);
+    if (dtype == IMH_DT_F16) return ew_typed<f16_t>(op, p, stream);
+    set_error("elementwise: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
+}
+
+}  // namespace imh

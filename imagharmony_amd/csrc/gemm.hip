@@ -1,0 +1,384 @@
+// MFMA GEMM / implicit-GEMM conv3x3 for gfx950.
+//
+//   Y[m, n] = epilogue( sum_k X[m, k] * W[n, k] )          (both operands K-contiguous)
+//
+// One kernel family serves every dense contraction of the SDXL UNet hot path
+// (SURVEY.md 2.2): Linear layers (to_q/to_k/to_v/to_out, proj_in/out, GEGLU, FF-out,
+// time/add embeddings), the 3x3 convolutions of ResnetBlock2D / Down/Upsample2D / conv_out
+// as an implicit GEMM over NHWC activations (K index = (ky*3+kx)*Cin + c), and the 1x1
+// shortcut convs.  Reference call sites: ip_adapter/attention_processor.py:292-300,320,
+// 396,410-411,432-433,453; diffusers UNet.
+//
+// Structure (cdna_hip_programming.md section 5, "step-3 + swizzle" with the T3/T4 minimum
+// two-phase loop): 256 threads = 2x2 waves, BK = 64, two LDS stages filled by
+// global_load_lds_dwordx4 (16 B/lane, destination lane-linear), XOR swizzle applied on the
+// SOURCE chunk and on the fragment READ (rule 21), v_mfma_f32_16x16x32 with the weight tile
+// as the MFMA A operand so that every lane ends up owning 4*FN consecutive output columns
+// (16-B vector epilogue).  Out-of-range rows and conv padding taps read a zero page, so the
+// K loop has no bounds branches.  Roofline: MFMA-bound (2.5 PFLOP/s dense bf16/f16).
+#include "imh_common.h"
+#include "imh_kernels.h"
+#include <algorithm>
+
+namespace imh {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+enum : int {
+    GF_GEGLU = 1,      // columns interleaved (value, gate): out[n/2] = a * gelu(g)
+    GF_ACT_GELU = 2,   // exact-erf GELU on the (biased) result
+    GF_ACT_SILU = 4,
+    GF_VT_PERM = 8,    // permute each 16-column group [0-3,8-11,4-7,12-15] (attention V^T layout)
+    GF_OUT_F32 = 16,   // store fp32 instead of T
+};
+
+template <typename T, int FN>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4 * FN], int m, int nb) {
+    constexpr int NV = 4 * FN;
+    // optional V^T key permutation inside each group of 16 columns (swap the 2nd and 3rd run of 4)
+    if ((p.flags & GF_VT_PERM) && FN == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float t = v[4 + r]; v[4 + r] = v[8 + r]; v[8 + r] = t; }
+    }
+    const T* bias = (const T*)p.bias;
+    const T* rowadd = (const T*)p.rowadd;
+    const T* res = (const T*)p.residual;
+    const int N = p.N;
+    if (bias) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] += to_f32(bias[nb + q]);
+    }
+    if (rowadd) {
+        const T* ra = rowadd + (size_t)(m / p.rows_per_batch) * p.ldra;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] += to_f32(ra[nb + q]);
+    }
+    if (p.flags & GF_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = gelu_erf_f(v[q]);
+    }
+    if (p.flags & GF_ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = silu_f(v[q]);
+    }
+    if (p.flags & GF_GEGLU) {
+        // (a, g) pairs -> NV/2 outputs at column nb/2
+        const int ob = nb >> 1;
+        const int NO = N >> 1;
+        T* y = (T*)p.Y + (size_t)m * p.ldy + ob;
+#pragma unroll
+        for (int q = 0; q < NV / 2; ++q) {
+            float o = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
+            if (res && ob + q < NO) o += to_f32(res[(size_t)m * p.ldr + ob + q]);
+            v[q] = o;
+        }
+        if (ob + NV / 2 <= NO) {
+            typename Vec<T>::v4 o4;
+#pragma unroll
+            for (int q0 = 0; q0 < NV / 2; q0 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = from_f32<T>(v[q0 + q]);
+                *(typename Vec<T>::v4*)(y + q0) = o4;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV / 2; ++q) if (ob + q < NO) y[q] = from_f32<T>(v[q]);
+        }
+        return;
+    }
+    if (res) {
+        const T* rr = res + (size_t)m * p.ldr + nb;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] += to_f32(rr[q]);
+    }
+    if (p.flags & GF_OUT_F32) {
+        float* y = (float*)p.Y + (size_t)m * p.ldy + nb;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) y[q] = v[q];
+        return;
+    }
+    T* y = (T*)p.Y + (size_t)m * p.ldy + nb;
+    if (nb + NV <= N && (p.ldy & 7) == 0) {
+#pragma unroll
+        for (int q0 = 0; q0 < NV; q0 += 8) {
+            typename Vec<T>::v8 o8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o8[q] = from_f32<T>(v[q0 + q]);
+            *(typename Vec<T>::v8*)(y + q0) = o8;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) y[q] = from_f32<T>(v[q]);
+    }
+}
+
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int FM = BM / 32;   // 16-row token fragments per wave
+    constexpr int FN = BN / 32;   // 16-row weight fragments per wave
+    constexpr int RX = BM / 32;   // staging rounds (32 rows per round per block)
+    constexpr int RW = BN / 32;
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int WT_BYTES = BN * GEMM_ROW_BYTES;
+    constexpr int STAGE = XT_BYTES + WT_BYTES;
+    typedef typename Vec<T>::v8 v8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- tile coordinates; blockIdx.x walks N fastest inside an M panel so that concurrently
+    //      resident blocks share the token panel in L2 ----
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    // ---- split-K range ----
+    const int nkt = p.K / GEMM_BK;
+    const int z = blockIdx.y;
+    const int per = (nkt + p.splits - 1) / p.splits;
+    const int kt0 = z * per;
+    const int kt1 = min(nkt, kt0 + per);
+
+    // ---- per-thread staging state ----
+    const unsigned char* zero = g_zero_page;
+
+    const unsigned char* xbase[RX];
+    int xstep[RX];
+    // conv decomposition of the output pixel handled by this staging row
+    int cb[RX], coy[RX], cox[RX];
+    bool cvalid[RX];
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int row = stage_row(i, wave, lane);
+        const int c = stage_chunk_x(row, lane);
+        const int m = m0 + row;
+        if (!CONV) {
+            const bool ok = m < p.M;
+            xbase[i] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+            xstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+        } else {
+            const bool ok = m < p.M;
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wo;
+            cb[i] = b; coy[i] = oy; cox[i] = rem - oy * p.Wo; cvalid[i] = ok;
+            xbase[i] = zero + c * 16;
+            xstep[i] = 0;
+        }
+    }
+    const unsigned char* wbase[RW];
+    int wstep[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int row = stage_row(i, wave, lane);
+        const int c = stage_chunk_w(row, lane, FN);
+        const int n = n0 + row;
+        const bool ok = n < p.N;
+        wbase[i] = ok ? (const unsigned char*)p.W + ((size_t)n * p.ldw) * sizeof(T) + c * 16 : zero + c * 16;
+        wstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+    }
+    const int cpt = CONV ? p.Cin / GEMM_BK : 1;   // k-tiles per conv tap
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* ws = xs + XT_BYTES;
+        if (CONV) {
+            const int tap = kt / cpt;
+            const int ct = kt - tap * cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+#pragma unroll
+            for (int i = 0; i < RX; ++i) {
+                const int c = stage_chunk_x(stage_row(i, wave, lane), lane);
+                const int iy = coy[i] * p.stride + ky - 1;
+                const int ix = cox[i] * p.stride + kx - 1;
+                const bool ok = cvalid[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                const size_t pix = ((size_t)cb[i] * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
+                const unsigned char* src = ok
+                    ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
+                    : zero + c * 16;
+                glds16(src, xs + stage_lds_off(i, wave));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RX; ++i)
+                glds16(xbase[i] + (size_t)kt * xstep[i], xs + stage_lds_off(i, wave));
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            glds16(wbase[i] + (size_t)kt * wstep[i], ws + stage_lds_off(i, wave));
+    };
+
+    // ---- per-lane fragment read offsets ----
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        xoff[kk] = xfrag_off(lane, wm, BM, kk);
+        woff[kk] = wfrag_off(lane, wn, BN, kk);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        stage(0, kt0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA landed (also implied by the fence below)
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+            const unsigned char* xs = smem + cur * STAGE;
+            const unsigned char* ws = xs + XT_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                v8 xf[FM], wf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) xf[i] = *(const v8*)(xs + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(ws + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: lane owns columns nb .. nb+4*FN-1 of row m ----
+    const int nb = n0 + out_col(lane, wn, BN);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + out_row(lane, wm, BM, i);
+        if (m >= p.M || nb >= p.N) continue;
+        float v[4 * FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+        if (p.splits > 1) {
+            float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+            if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+#pragma unroll
+                for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+            }
+        } else {
+            epilogue_store<T, FN>(p, v, m, nb);
+        }
+    }
+}
+
+// split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const int groups_n = (p.N + 15) / 16;
+    const size_t total = (size_t)p.M * groups_n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / groups_n);
+        const int nb = (int)(idx % groups_n) * 16;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = 0.f;
+        for (int z = 0; z < p.splits; ++z) {
+            const float* s = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+            if (nb + 16 <= p.N && (p.N & 3) == 0) {
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 4) {
+                    f32x4 t = *(const f32x4*)(s + q0);
+                    v[q0] += t[0]; v[q0 + 1] += t[1]; v[q0 + 2] += t[2]; v[q0 + 3] += t[3];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (nb + q < p.N) v[q] += s[q];
+            }
+        }
+        GemmParams q = p;
+        epilogue_store<T, 4>(q, v, m, nb);
+    }
+}
+
+template <typename T, int BM, int BN, bool CONV>
+static int launch_tile(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
+    dim3 grid(tiles, p.splits, 1);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV>), grid, dim3(256), smem, stream, p);
+    return check_launch("gemm_kernel");
+}
+
+template <typename T>
+static int launch_typed(const GemmParams& p, int conv, int bm, int bn, hipStream_t stream) {
+    int rc;
+    if (conv) {
+        if (bm == 128 && bn == 128) rc = launch_tile<T, 128, 128, true>(p, stream);
+        else if (bm == 128 && bn == 64) rc = launch_tile<T, 128, 64, true>(p, stream);
+        else if (bm == 64 && bn == 128) rc = launch_tile<T, 64, 128, true>(p, stream);
+        else if (bm == 64 && bn == 64) rc = launch_tile<T, 64, 64, true>(p, stream);
+        else { set_error("gemm: unsupported tile %dx%d", bm, bn); return IMH_ERR_ARG; }
+    } else {
+        if (bm == 128 && bn == 128) rc = launch_tile<T, 128, 128, false>(p, stream);
+        else if (bm == 128 && bn == 64) rc = launch_tile<T, 128, 64, false>(p, stream);
+        else if (bm == 64 && bn == 128) rc = launch_tile<T, 64, 128, false>(p, stream);
+        else if (bm == 64 && bn == 64) rc = launch_tile<T, 64, 64, false>(p, stream);
+        else { set_error("gemm: unsupported tile %dx%d", bm, bn); return IMH_ERR_ARG; }
+    }
+    if (rc != IMH_OK) return rc;
+    if (p.splits > 1) {
+        const size_t total = (size_t)p.M * ((p.N + 15) / 16);
+        int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+        rc = check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}
+
+// heuristic tile / split-K choice; overridable per call (bm/bn/splits > 0)
+void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
+    const int CUS = 256;
+    int cbm = 128, cbn = 128;
+    auto tiles = [&](int a, int b) { return ((M + a - 1) / a) * ((N + b - 1) / b); };
+    if (N <= 64) cbn = 64;
+    if (M <= 64) cbm = 64;
+    if (tiles(cbm, cbn) < 2 * CUS && cbn == 128 && N % 128 != 0 && N % 64 == 0) cbn = 64;
+    if (tiles(cbm, cbn) < CUS && cbn == 128) cbn = 64;
+    if (tiles(cbm, cbn) < CUS && cbm == 128) cbm = 64;
+    int s = 1;
+    const int nkt = K / GEMM_BK;
+    while (tiles(cbm, cbn) * s < CUS && s * 2 <= 8 && nkt / (s * 2) >= 4) s *= 2;
+    *bm = cbm; *bn = cbn; *splits = s;
+}
+
+size_t gemm_workspace_bytes(int M, int N, int splits) {
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream) {
+    if (p.K % GEMM_BK != 0 || p.K <= 0) { set_error("gemm: K=%d must be a positive multiple of 64", p.K); return IMH_ERR_SHAPE; }
+    if (conv && (p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin)) { set_error("conv3x3: Cin=%d must be a multiple of 64 and K=9*Cin", p.Cin); return IMH_ERR_SHAPE; }
+    if (!conv && ((p.ldx & 7) || (p.ldw & 7))) { set_error("gemm: ldx/ldw must be multiples of 8 elements"); return IMH_ERR_SHAPE; }
+    if (p.M <= 0 || p.N <= 0) { set_error("gemm: empty problem M=%d N=%d", p.M, p.N); return IMH_ERR_SHAPE; }
+    if ((p.flags & GF_GEGLU) && (p.N & 15)) { set_error("geglu: N must be a multiple of 16"); return IMH_ERR_SHAPE; }
+    if (p.splits < 1) p.splits = 1;
+    if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
+    if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
+    if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);
+    if (dtype == IMH_DT_F16) return launch_typed<f16_t>(p, conv, bm, bn, stream);
+    set_error("gemm: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
+}
+
+}  // namespace imh

@@ -1,0 +1,86 @@
+// Common device helpers for the gfx950 (CDNA4 / MI355X) kernels.  gfx950 only: no
+// compatibility macros, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "imh_layout.h"
+
+namespace imh {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct Vec<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };
+
+// ---- MFMA wrappers (cdna_hip_programming.md section 3) ----
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- async global -> LDS copy, 16 B per lane, destination = lds_base + lane*16 ----
+// lds_base must be wave-uniform (it travels in M0).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// a 256-B page of zeros: out-of-range tile rows / conv padding taps fetch from here, so
+// the main loops carry no bounds branches
+extern __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace imh
+
+// ---- status codes of the C ABI (include/imh.h) ----
+#define IMH_OK 0
+#define IMH_ERR_ARG (-1)
+#define IMH_ERR_SHAPE (-2)
+#define IMH_ERR_DTYPE (-3)
+#define IMH_ERR_LAUNCH (-4)
+#define IMH_ERR_WORKSPACE (-5)
+
+#define IMH_DT_BF16 0
+#define IMH_DT_F16 1
+
+namespace imh {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}

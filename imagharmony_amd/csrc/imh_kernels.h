@@ -1,0 +1,76 @@
+// Internal launcher interface between the C ABI (api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace imh {
+
+struct GemmParams {
+    const void* X;         // [M, K] tokens (ldx) -- or NHWC conv input [B, H, Wd, Cin]
+    const void* W;         // [N, K] weights, K contiguous (ldw)
+    void* Y;               // [M, ldy] output (T, or fp32 with GF_OUT_F32)
+    float* partial;        // split-K slabs [splits][M][N] fp32
+    const void* bias;      // [N] or null
+    const void* rowadd;    // [M / rows_per_batch, N] broadcast add (time-embedding projection) or null
+    const void* residual;  // [M, ldr] or null (added after activation / GEGLU)
+    int M, N, K;
+    int ldx, ldw, ldy, ldr, ldra;
+    int rows_per_batch;
+    int splits;
+    int flags;
+    // implicit-GEMM conv3x3 (pad 1): input H x Wd (virtual size << up), output Ho x Wo
+    int H, Wd, Cin, Ho, Wo, stride, up;
+};
+
+void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
+size_t gemm_workspace_bytes(int M, int N, int splits);
+int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
+
+struct AttnParams {
+    const void* Q;    // [B, Lq, ldq] (+ head*64 columns)
+    const void* K;    // [B, Lk_pad, ldk] keys, row-major per key
+    const void* Vt;   // [H*64, ldvt] V transposed, keys permuted in 16-groups; batch b at column b*Lk_pad
+    const void* K2;   // optional second (image-prompt) key set, same layouts
+    const void* Vt2;
+    void* O;          // [B, Lq, ldo]
+    int B, H, Lq;
+    int Lk, Lk_pad;   // valid keys / padded row count per batch (multiple of 64)
+    int Lk2, Lk2_pad;
+    int ldq, ldk, ldvt, ldk2, ldvt2, ldo;
+    float scale;      // softmax scale (1/sqrt(64))
+    float scale2;     // weight of the second attention (IP scale)
+    const float* scale2_tab;  // optional per-step table of IP scales, indexed by *step
+    const int* step;
+};
+int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
+
+struct NormParams {
+    const void* x;
+    void* y;
+    const void* gamma;
+    const void* beta;
+    float* partial;   // group-norm partial sums workspace
+    int B, HW, C, groups;
+    int rows;         // layer norm: rows
+    float eps;
+    int silu;
+};
+int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream);
+size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int layernorm_launch(const NormParams& p, int dtype, hipStream_t stream);
+
+struct EwParams {
+    const void* a;
+    const void* b;
+    void* y;
+    const void* w;
+    const void* bias;
+    const float* tab;   // optional per-step scalar table
+    const int* step;    // device-resident denoise step counter
+    long long n;
+    int i0, i1, i2, i3, i4, i5;
+    float f0, f1, f2, f3;
+};
+int ew_launch(int op, const EwParams& p, int dtype, hipStream_t stream);
+
+}  // namespace imh

@@ -1,0 +1,216 @@
+// GroupNorm(32)+SiLU over NHWC activations and LayerNorm over token rows, gfx950.
+// HBM-bound kernels: 16-B vector loads/stores, fp32 statistics (PyTorch semantics:
+// GroupNorm / LayerNorm accumulate in fp32 whatever the activation dtype).
+// Call sites being replaced: diffusers ResnetBlock2D.norm1/norm2 (+SiLU), Transformer2DModel.norm
+// (eps 1e-6, no SiLU), conv_norm_out, BasicTransformerBlock.norm1/2/3;
+// ImageProjModel.norm (ip_adapter/ip_adapter.py:39,47), Resampler norms (resampler.py:15,42-43,104),
+// HarmonyAttention.ln (train.py:238).
+#include "imh_common.h"
+#include "imh_kernels.h"
+
+namespace imh {
+
+constexpr int GN_THREADS = 512;
+constexpr int GN_ELEMS_PER_BLOCK = 32768;
+
+static inline int gn_nblk(int HW, int C) {
+    long long e = (long long)HW * C;
+    int n = (int)((e + GN_ELEMS_PER_BLOCK - 1) / GN_ELEMS_PER_BLOCK);
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
+}
+
+size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
+    return (size_t)B * gn_nblk(HW, C) * groups * 2 * sizeof(float);
+}
+
+// pass 1: per-(batch, block, group) partial sum / sum of squares.
+// thread t < CL*P: channel chunk cl = t % CL (8 channels), pixel lane pl = t / CL.
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p, int nblk) {
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ float lds[];   // [2][C]
+    const int C = p.C, CL = C >> 3;
+    const int P = max(1, GN_THREADS / CL);
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int ppb = (p.HW + nblk - 1) / nblk;
+    const int start = blk * ppb, end = min(p.HW, start + ppb);
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * C; i += GN_THREADS) lds[i] = 0.f;
+    __syncthreads();
+    if (t < CL * P) {
+        const int cl = t % CL, pl = t / CL;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
+        for (int pix = start + pl; pix < end; pix += P) {
+            v8 v = *(const v8*)(x + (size_t)pix * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float f = to_f32(v[e]); s[e] += f; q[e] += f * f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&lds[cl * 8 + e], s[e]);
+            atomicAdd(&lds[C + cl * 8 + e], q[e]);
+        }
+    }
+    __syncthreads();
+    if (t < p.groups) {
+        const int cpg = C / p.groups;
+        float s = 0.f, q = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += lds[c]; q += lds[C + c]; }
+        float* o = p.partial + (((size_t)b * nblk + blk) * p.groups + t) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// pass 2: finalise statistics (double), then y = silu?(x * scale[c] + shift[c]).
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk) {
+    typedef typename Vec<T>::v8 v8;
+    __shared__ float mean_s[64], rstd_s[64];
+    const int C = p.C, CL = C >> 3;
+    const int P = max(1, GN_THREADS / CL);
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int ppb = (p.HW + nblk - 1) / nblk;
+    const int start = blk * ppb, end = min(p.HW, start + ppb);
+    const int t = threadIdx.x;
+    if (t < p.groups) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            const float* pp = p.partial + (((size_t)b * nblk + k) * p.groups + t) * 2;
+            s += pp[0]; q += pp[1];
+        }
+        const double n = (double)p.HW * (C / p.groups);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[t] = (float)mean;
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    if (t < CL * P) {
+        const int cl = t % CL, pl = t / CL;
+        const int cpg = C / p.groups;
+        float sc[8], sh[8];
+        const T* ga = (const T*)p.gamma;
+        const T* be = (const T*)p.beta;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cl * 8 + e;
+            const int g = c / cpg;
+            const float gm = ga ? to_f32(ga[c]) : 1.f;
+            const float bt = be ? to_f32(be[c]) : 0.f;
+            sc[e] = gm * rstd_s[g];
+            sh[e] = bt - mean_s[g] * sc[e];
+        }
+        const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
+        T* y = (T*)p.y + ((size_t)b * p.HW) * C + cl * 8;
+        for (int pix = start + pl; pix < end; pix += P) {
+            v8 v = *(const v8*)(x + (size_t)pix * C);
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = to_f32(v[e]) * sc[e] + sh[e];
+                if (p.silu) f = silu_f(f);
+                o[e] = from_f32<T>(f);
+            }
+            *(v8*)(y + (size_t)pix * C) = o;
+        }
+    }
+}
+
+int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
+    if (p.C % 8 || p.groups <= 0 || p.groups > 64 || p.C % p.groups || (p.C >> 3) > GN_THREADS) {
+        set_error("groupnorm: unsupported C=%d groups=%d", p.C, p.groups);
+        return IMH_ERR_SHAPE;
+    }
+    if (!p.partial) { set_error("groupnorm: workspace missing"); return IMH_ERR_WORKSPACE; }
+    const int nblk = gn_nblk(p.HW, p.C);
+    dim3 grid(nblk, p.B);
+    const size_t lds = 2 * (size_t)p.C * sizeof(float);
+    if (dtype == IMH_DT_BF16) {
+        hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
+        hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+    } else if (dtype == IMH_DT_F16) {
+        hipLaunchKernelGGL((gn_stats_kernel<f16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
+        hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+    } else { set_error("groupnorm: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    return check_launch("groupnorm");
+}
+
+// ---- LayerNorm: one wave per row, the row lives in registers (C <= 4096) ----
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_kernel(const NormParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int C = p.C, CL = C >> 3;
+    const T* x = (const T*)p.x + (size_t)row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < CL) {
+            v8 t = *(const v8*)(x + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = to_f32(t[e]); s += v[k][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < CL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
+    const T* ga = (const T*)p.gamma;
+    const T* be = (const T*)p.beta;
+    T* y = (T*)p.y + (size_t)row * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < CL) {
+            v8 g8, b8, o;
+            if (ga) g8 = *(const v8*)(ga + ch * 8);
+            if (be) b8 = *(const v8*)(be + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (v[k][e] - mean) * rstd;
+                if (ga) f *= to_f32(g8[e]);
+                if (be) f += to_f32(b8[e]);
+                o[e] = from_f32<T>(f);
+            }
+            *(v8*)(y + ch * 8) = o;
+        }
+    }
+}
+
+template <typename T>
+static int ln_typed(const NormParams& p, hipStream_t stream) {
+    dim3 grid((p.rows + 3) / 4);
+    const int cl = p.C >> 3;
+    if (cl <= 128) hipLaunchKernelGGL((ln_kernel<T, 2>), grid, dim3(256), 0, stream, p);
+    else if (cl <= 256) hipLaunchKernelGGL((ln_kernel<T, 4>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((ln_kernel<T, 8>), grid, dim3(256), 0, stream, p);
+    return check_launch("ln_kernel");
+}
+
+int layernorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
+    if (p.C % 8 || p.C > 4096 || p.rows <= 0) { set_error("layernorm: unsupported C=%d rows=%d", p.C, p.rows); return IMH_ERR_SHAPE; }
+    if (dtype == IMH_DT_BF16) return ln_typed<bf16_t>(p, stream);
+    if (dtype == IMH_DT_F16) return ln_typed<f16_t>(p, stream);
+    set_error("layernorm: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
+}
+
+}  // namespace imh

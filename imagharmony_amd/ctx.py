@@ -1,0 +1,313 @@
+"""Execution context: maps torch tensors (device memory + streams only -- plumbing) onto the
+C ABI of libimh_hip.so, either eagerly (one ctypes call per op) or by RECORDING the calls into a
+C++ plan that is later replayed / captured into a hipGraph (one UNet forward is ~1000 launches;
+issuing them from Python would cost more than the GPU time).
+
+Nothing here computes with torch: tensors are allocated, viewed and handed over as raw pointers.
+"""
+import ctypes as C
+import json
+import os
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.bfloat16: L.IMH_DT_BF16, torch.float16: L.IMH_DT_F16}
+_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning.json")
+
+
+def _load_tuning():
+    try:
+        with open(_TUNING_PATH) as f:
+            raw = json.load(f)
+        return {tuple(int(v) for v in k.split(",")): tuple(cfg) for k, cfg in raw.items()}
+    except (OSError, ValueError):
+        return {}
+
+
+class Ctx:
+    def __init__(self, device, dtype=torch.bfloat16, record=False, dry=False):
+        """dry=True (record only): tensors may live on the CPU; the plan can be inspected (op list,
+        FLOP / byte accounting) but never run -- used by the host-logic tests, not a compute path."""
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.dry = bool(dry and record)
+        if self.device.type != "cuda" and not self.dry:
+            raise L.ImhError("imagharmony_amd needs a ROCm device (there is no CPU path)")
+        if dtype not in _DT:
+            raise L.ImhError(f"unsupported compute dtype {dtype}")
+        self.dtype = dtype
+        self.dt = _DT[dtype]
+        self.record = record
+        self.plan = self.lib.imh_plan_create() if record else None
+        self.keep = []          # tensors referenced by recorded ops
+        self.tag = 0
+        self.tags = []          # per recorded op: (tag, kind, descr, flops, bytes)
+        self._pool = {}
+        self._bases = {}        # storage ptr -> pool-owned base tensor
+        self._live = set()
+        self._ws = None
+        self.tuning = _load_tuning()
+        self.captured = False
+
+    # ------------------------------------------------------------------ memory
+    def new(self, *shape, dtype=None):
+        dtype = dtype or self.dtype
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nb = n * torch.empty((), dtype=dtype).element_size()
+        key = (nb + 255) // 256 * 256
+        lst = self._pool.get(key)
+        if lst:
+            base = lst.pop()
+        else:
+            base = torch.empty(key, dtype=torch.uint8, device=self.device)
+            self._bases[base.data_ptr()] = base
+            if self.record:
+                self.keep.append(base)
+        self._live.add(base.data_ptr())
+        return base[:nb].view(dtype).view(*shape)
+
+    def free(self, t):
+        """Return an activation buffer (or any view of it) to the pool.  Only legal once every op
+        that reads it has been emitted (stream order makes later reuse safe)."""
+        ptr = t.untyped_storage().data_ptr()
+        base = self._bases.get(ptr)
+        if base is None:
+            return                      # not pool-owned (weights, caller tensors)
+        if ptr not in self._live:
+            raise L.ImhError("Ctx.free: buffer freed twice")
+        self._live.discard(ptr)
+        self._pool.setdefault(base.numel(), []).append(base)
+
+    def zeros(self, *shape, dtype=None):
+        t = torch.zeros(*shape, dtype=dtype or self.dtype, device=self.device)
+        if self.record:
+            self.keep.append(t)
+        return t
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=self.device)
+            if self.record:
+                self.keep.append(self._ws)
+        return self._ws
+
+    def stream(self):
+        if self.dry:
+            raise L.ImhError("a dry-run context cannot execute (no CPU path)")
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ emit
+    def _emit(self, kind, args, ew_op=0, descr="", flops=0.0, nbytes=0.0, keep=(), shape=None):
+        if self.record:
+            rc = self.lib.imh_plan_add(self.plan, kind, C.byref(args), ew_op, self.tag)
+            if rc < 0:
+                L.check(rc, "imh_plan_add")
+            self.keep.extend(k for k in keep if k is not None)
+            self.tags.append((self.tag, kind, descr, flops, nbytes, shape))
+            return
+        s = self.stream()
+        if kind == L.OP_GEMM:
+            rc = self.lib.imh_gemm(C.byref(args), s)
+        elif kind == L.OP_ATTN:
+            rc = self.lib.imh_attention(C.byref(args), s)
+        elif kind == L.OP_GROUPNORM:
+            rc = self.lib.imh_groupnorm(C.byref(args), s)
+        elif kind == L.OP_LAYERNORM:
+            rc = self.lib.imh_layernorm(C.byref(args), s)
+        else:
+            rc = self.lib.imh_elementwise(ew_op, C.byref(args), s)
+        L.check(rc, descr or f"op kind {kind}")
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else t.data_ptr()
+
+    def _chk(self, t, name, dtype=None):
+        if t is None:
+            return
+        if t.device != self.device and not (t.device.type == "cuda" and t.device.index == (self.device.index or 0)):
+            raise L.ImhError(f"{name}: tensor on {t.device}, context on {self.device}")
+        if t.dtype != (dtype or self.dtype):
+            raise L.ImhError(f"{name}: dtype {t.dtype}, expected {dtype or self.dtype}")
+
+    # ------------------------------------------------------------------ GEMM / conv
+    def _config(self, M, N, K, conv, flags):
+        key = (M, N, K, int(conv))
+        if key in self.tuning:
+            return self.tuning[key]
+        bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
+        self.lib.imh_gemm_pick_config(M, N, K, C.byref(bm), C.byref(bn), C.byref(sp))
+        return bm.value, bn.value, sp.value
+
+    def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
+             M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None):
+        """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous."""
+        self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
+        M = M if M is not None else x.shape[0]
+        K = K if K is not None else x.shape[1]
+        N = N if N is not None else w.shape[0]
+        if x.stride(-1) != 1 or w.stride(-1) != 1:
+            raise L.ImhError(f"{descr}: operands must be contiguous in K")
+        n_out = N // 2 if flags & L.GF_GEGLU else N
+        if out is None:
+            out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
+        bm, bn, sp = cfg or self._config(M, N, K, 0, flags)
+        a = L.GemmArgs()
+        a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
+        a.M, a.N, a.K = M, N, K
+        a.ldx = ldx if ldx is not None else x.stride(0)
+        a.ldw = ldw if ldw is not None else w.stride(0)
+        a.ldy = ldy if ldy is not None else out.stride(0)
+        a.ldr = (ldr if ldr is not None else residual.stride(0)) if residual is not None else 0
+        a.ldra = ldra
+        a.rows_per_batch = rows_per_batch
+        a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, flags, self.dt, 0, bm, bn
+        if sp > 1:
+            a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
+        es = x.element_size()
+        self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
+                   keep=(x, w, out, bias, rowadd, residual), shape=(M, N, K, 0, None))
+        return out
+
+    def conv3x3(self, x, w, bias=None, stride=1, up=0, residual=None, rowadd=None, ldra=0, out=None, cfg=None,
+                descr="conv3x3"):
+        """x: NHWC [B, H, W, Cin]; w: packed [Cout, 9*Cin]; returns NHWC [B, Ho, Wo, Cout]."""
+        self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        Hv, Wv = H << up, W << up
+        Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
+        M, N, K = B * Ho * Wo, Cout, 9 * Cin
+        if not x.is_contiguous() or not w.is_contiguous() or w.shape[1] != K:
+            raise L.ImhError(f"{descr}: x must be contiguous NHWC and w packed [Cout, 9*Cin]")
+        if out is None:
+            out = self.new(B, Ho, Wo, Cout)
+        bm, bn, sp = cfg or self._config(M, N, K, 1, 0)
+        a = L.GemmArgs()
+        a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
+        a.M, a.N, a.K = M, N, K
+        a.ldx, a.ldw, a.ldy = Cin, K, Cout
+        a.ldr = Cout if residual is not None else 0
+        a.ldra = ldra
+        a.rows_per_batch = Ho * Wo
+        a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, 0, self.dt, 1, bm, bn
+        a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
+        if sp > 1:
+            a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
+        es = x.element_size()
+        self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K,
+                   nbytes=es * (B * H * W * Cin + N * K + M * N), keep=(x, w, out, bias, rowadd, residual),
+                   shape=(M, N, K, 1, (B, H, W, Cin, stride, up)))
+        return out
+
+    # ------------------------------------------------------------------ attention
+    def attention(self, q, k, vt, out, B, H, Lq, Lk, Lk_pad, ldq, ldk, ldvt, ldo, scale,
+                  k2=None, vt2=None, Lk2=0, Lk2_pad=0, ldk2=0, ldvt2=0, scale2=0.0, scale2_tab=None, step=None,
+                  descr="attention"):
+        a = L.AttnArgs()
+        a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+        a.K2, a.Vt2 = self._p(k2), self._p(vt2)
+        a.B, a.H, a.Lq, a.Lk, a.Lk_pad, a.Lk2, a.Lk2_pad = B, H, Lq, Lk, Lk_pad, Lk2, Lk2_pad
+        a.ldq, a.ldk, a.ldvt, a.ldk2, a.ldvt2, a.ldo = ldq, ldk, ldvt, ldk2, ldvt2, ldo
+        a.scale, a.scale2, a.dtype = scale, scale2, self.dt
+        a.scale2_tab, a.step = self._p(scale2_tab), self._p(step)
+        es = q.element_size()
+        fl = 4.0 * B * H * Lq * (Lk + Lk2) * 64
+        by = es * (2 * B * Lq * H * 64 + 2 * B * (Lk + Lk2) * H * 64)
+        self._emit(L.OP_ATTN, a, descr=descr, flops=fl, nbytes=by, keep=(q, k, vt, out, k2, vt2, scale2_tab, step))
+        return out
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm"):
+        """x: [B, HW, C] (NHWC flattened)."""
+        self._chk(x, descr + ".x")
+        B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+        if out is None:
+            out = self.new(*x.shape)
+        a = L.NormArgs()
+        a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(gamma), self._p(beta)
+        # scratch use is confined to this op's two kernels (stream order), so the shared workspace is safe
+        a.partial = self.workspace(self.lib.imh_groupnorm_workspace_bytes(B, HW, Cc, groups)).data_ptr()
+        a.B, a.HW, a.C, a.groups, a.eps, a.silu, a.dtype = B, HW, Cc, groups, eps, int(silu), self.dt
+        es = x.element_size()
+        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=3.0 * es * x.numel(),
+                   keep=(x, out, gamma, beta))
+        return out
+
+    def layernorm(self, x, gamma, beta, eps, out=None, descr="layernorm"):
+        self._chk(x, descr + ".x")
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        if out is None:
+            out = self.new(*x.shape)
+        a = L.NormArgs()
+        a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(gamma), self._p(beta)
+        a.rows, a.C, a.eps, a.dtype = rows, Cc, eps, self.dt
+        es = x.element_size()
+        self._emit(L.OP_LAYERNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=2.0 * es * x.numel(),
+                   keep=(x, out, gamma, beta))
+        return out
+
+    # ------------------------------------------------------------------ elementwise
+    def ew(self, op, y, a=None, b=None, w=None, bias=None, tab=None, step=None, n=0, i=(0, 0, 0, 0, 0, 0),
+           f=(0.0, 0.0, 0.0, 0.0), descr="ew", nbytes=0.0):
+        e = L.EwArgs()
+        e.a, e.b, e.y, e.w, e.bias = self._p(a), self._p(b), y.data_ptr(), self._p(w), self._p(bias)
+        e.tab, e.step = self._p(tab), self._p(step)
+        e.n = n
+        e.i0, e.i1, e.i2, e.i3, e.i4, e.i5 = i
+        e.f0, e.f1, e.f2, e.f3 = f
+        e.dtype = self.dt
+        self._emit(L.OP_EW, e, ew_op=op, descr=descr, nbytes=nbytes, keep=(a, b, y, w, bias, tab, step))
+        return y
+
+    def silu(self, x, descr="silu"):
+        out = self.new(*x.shape)
+        return self.ew(L.EW_SILU, out, a=x, n=x.numel(), descr=descr, nbytes=2.0 * x.numel() * x.element_size())
+
+    def concat(self, a, b, descr="concat"):
+        """NHWC channel concat: a [..., C1], b [..., C2] -> [..., C1 + C2]."""
+        c1, c2 = a.shape[-1], b.shape[-1]
+        pix = a.numel() // c1
+        out = self.new(*a.shape[:-1], c1 + c2)
+        return self.ew(L.EW_CONCAT, out, a=a, b=b, n=pix, i=(c1, c2, 0, 0, 0, 0), descr=descr,
+                       nbytes=2.0 * out.numel() * out.element_size())
+
+    # ------------------------------------------------------------------ plans
+    def run(self):
+        L.check(self.lib.imh_plan_run(self.plan, self.stream()), "imh_plan_run")
+
+    def capture(self):
+        """Capture the recorded plan into a hipGraph (needs a non-default stream)."""
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            L.check(self.lib.imh_plan_capture(self.plan, C.c_void_p(s.cuda_stream)), "imh_plan_capture")
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self.captured = True
+
+    def replay(self):
+        if self.captured:
+            L.check(self.lib.imh_plan_replay(self.plan, self.stream()), "imh_plan_replay")
+        else:
+            self.run()
+
+    def time_ops(self):
+        n = self.lib.imh_plan_size(self.plan)
+        ms = (C.c_float * n)()
+        L.check(self.lib.imh_plan_time_ops(self.plan, self.stream(), ms, n), "imh_plan_time_ops")
+        return list(ms)
+
+    def __del__(self):
+        try:
+            if self.plan:
+                self.lib.imh_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass

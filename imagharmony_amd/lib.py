@@ -1,0 +1,108 @@
+"""ctypes binding of libimh_hip.so (include/imh.h).
+
+The product path has NO CPU fallback: if the shared library is missing or fails to load,
+importing any op raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(hipcc --offload-arch=gfx950, in-tree).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimh_hip.so")
+
+IMH_DT_BF16, IMH_DT_F16 = 0, 1
+GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32 = 1, 2, 4, 8, 16
+OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW = 0, 1, 2, 3, 4
+EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET = range(8)
+
+_i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
+                ("residual", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32),
+                ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
+                ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
+                ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("stride", _i32), ("up", _i32),
+                ("dtype", _i32), ("conv", _i32), ("bm", _i32), ("bn", _i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", _vp), ("K", _vp), ("Vt", _vp), ("K2", _vp), ("Vt2", _vp), ("O", _vp),
+                ("B", _i32), ("H", _i32), ("Lq", _i32), ("Lk", _i32), ("Lk_pad", _i32), ("Lk2", _i32),
+                ("Lk2_pad", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldvt", _i32), ("ldk2", _i32), ("ldvt2", _i32), ("ldo", _i32),
+                ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32)]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("partial", _vp),
+                ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("rows", _i32),
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32)]
+
+
+class EwArgs(C.Structure):
+    _fields_ = [("a", _vp), ("b", _vp), ("y", _vp), ("w", _vp), ("bias", _vp), ("tab", _vp), ("step", _vp),
+                ("n", C.c_int64),
+                ("i0", _i32), ("i1", _i32), ("i2", _i32), ("i3", _i32), ("i4", _i32), ("i5", _i32),
+                ("f0", _f32), ("f1", _f32), ("f2", _f32), ("f3", _f32), ("dtype", _i32)]
+
+
+# every symbol include/imh.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("imh_abi_version", C.c_int, []),
+    ("imh_last_error", C.c_char_p, []),
+    ("imh_gemm", C.c_int, [C.POINTER(GemmArgs), _vp]),
+    ("imh_gemm_pick_config", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]),
+    ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("imh_attention", C.c_int, [C.POINTER(AttnArgs), _vp]),
+    ("imh_groupnorm", C.c_int, [C.POINTER(NormArgs), _vp]),
+    ("imh_groupnorm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("imh_layernorm", C.c_int, [C.POINTER(NormArgs), _vp]),
+    ("imh_elementwise", C.c_int, [C.c_int, C.POINTER(EwArgs), _vp]),
+    ("imh_plan_create", _vp, []),
+    ("imh_plan_destroy", None, [_vp]),
+    ("imh_plan_add", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    ("imh_plan_size", C.c_int, [_vp]),
+    ("imh_plan_update", C.c_int, [_vp, C.c_int, _vp]),
+    ("imh_plan_run", C.c_int, [_vp, _vp]),
+    ("imh_plan_run_range", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("imh_plan_capture", C.c_int, [_vp, _vp]),
+    ("imh_plan_replay", C.c_int, [_vp, _vp]),
+    ("imh_plan_time_ops", C.c_int, [_vp, _vp, C.POINTER(C.c_float), C.c_int]),
+    ("imh_plan_get_tag", C.c_int, [_vp, C.c_int]),
+    ("imh_plan_get_kind", C.c_int, [_vp, C.c_int]),
+]
+
+_lib = None
+
+
+class ImhError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libimh_hip.so (once).  Raises ImhError if it is not built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImhError(f"{LIB_PATH} is missing: build the HIP extension first "
+                       f"(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.imh_abi_version() != 1:
+        raise ImhError("libimh_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().imh_last_error()
+        raise ImhError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,591 @@
+"""SDXL ``UNet2DConditionModel`` forward on the gfx950 kernels.
+
+What the reference calls at ip_adapter/custom_pipelines.py:338-345 / train.py:310 is diffusers' UNet
+(third-party; architecture per SURVEY.md Appendix A).  This module keeps its contract -- the SDXL
+state-dict key schema, ``.config``, ``.attn_processors``, ``.set_attn_processor(dict)``, and
+``forward(sample, timestep, encoder_hidden_states, added_cond_kwargs=..., return_dict=False)[0]`` --
+but the arithmetic is emitted as calls into libimh_hip.so:
+
+  * activations live token-major / NHWC ([B, H*W, C]) for the whole network, so the
+    NCHW<->token permutes of Transformer2DModel disappear and every 3x3 conv is an implicit GEMM
+    with a contiguous K axis; NCHW exists only at conv_in's input and after conv_out;
+  * GEGLU, bias, residual adds, time-embedding adds and nearest-upsampling are epilogue / gather
+    options of the GEMM kernel, not separate passes;
+  * the 17 ``time_emb_proj`` Linears are stacked into ONE GEMM per step;
+  * text / image-prompt K,V of the 70 cross-attention layers come from a per-image cache.
+
+torch is used for parameter storage and device memory only.  ``emit_forward`` records the whole
+forward into a ``Ctx`` (plan / hipGraph); ``forward`` is the eager drop-in signature.
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _w
+from .ctx import Ctx
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    sample_size: int = 128
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280)
+    layers_per_block: int = 2
+    transformer_layers_per_block: Tuple[int, ...] = (1, 2, 10)
+    attention_head_dim: Tuple[int, ...] = (5, 10, 20)
+    cross_attention_dim: int = 2048
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+
+    @property
+    def time_embed_dim(self):
+        return self.block_out_channels[0] * 4
+
+    @property
+    def pooled_dim(self):
+        return self.projection_class_embeddings_input_dim - 6 * self.addition_time_embed_dim
+
+    def get(self, k, d=None):
+        return getattr(self, k, d)
+
+
+# ------------------------------------------------------------------ parameter holders
+class Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(cout), requires_grad=False) if bias else None
+
+
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(cout), requires_grad=False)
+
+    def packed(self, ctx):
+        """[Cout, Cin, k, k] -> [Cout, k*k*Cin] (K index = (ky*k+kx)*Cin + c), cached."""
+        key = (self.weight.data_ptr(), ctx.dtype, str(ctx.device))
+        c = getattr(self, "_imh_packed", None)
+        if c is None or c[0] != key:
+            w = self.weight.detach().permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1)
+            c = (key, w.to(device=ctx.device, dtype=ctx.dtype).contiguous())
+            self._imh_packed = c
+        return c[1]
+
+
+class Norm(nn.Module):
+    def __init__(self, c, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(c), requires_grad=False)
+        self.eps = eps
+
+
+class Dropout(nn.Module):
+    pass
+
+
+class Attention(nn.Module):
+    """Parameter holder with the attribute surface the processors touch."""
+
+    def __init__(self, query_dim, heads, dim_head=64, cross_attention_dim=None):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        kv = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(kv, inner, bias=False)
+        self.to_v = Linear(kv, inner, bias=False)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim), Dropout()])
+        self.processor = AttnProcessor2_0()
+
+    def get_processor(self):
+        return self.processor
+
+    def set_processor(self, p):
+        if "processor" in self._modules and not isinstance(p, nn.Module):
+            self._modules.pop("processor")
+        self.processor = p
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = Linear(dim, inner * 2)
+
+    def packed(self, ctx):
+        """rows interleaved (value_q, gate_q) so one output tile holds both halves (GF_GEGLU epilogue)."""
+        key = (self.proj.weight.data_ptr(), ctx.dtype, str(ctx.device))
+        c = getattr(self, "_imh_packed", None)
+        if c is None or c[0] != key:
+            w, b = self.proj.weight.detach(), self.proj.bias.detach()
+            inner = w.shape[0] // 2
+            wi = torch.stack([w[:inner], w[inner:]], 1).reshape(2 * inner, -1)
+            bi = torch.stack([b[:inner], b[inner:]], 1).reshape(2 * inner)
+            c = (key, wi.to(device=ctx.device, dtype=ctx.dtype).contiguous(),
+                 bi.to(device=ctx.device, dtype=ctx.dtype).contiguous())
+            self._imh_packed = c
+        return c[1], c[2]
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), Dropout(), Linear(dim * 4, dim)])
+
+    def emit(self, ctx, x, residual):
+        w1, b1 = self.net[0].packed(ctx)
+        g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU, descr="ff.geglu")
+        out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out")
+        ctx.free(g)
+        return out
+
+
+def _ln(ctx, norm, x, descr):
+    return ctx.layernorm(x, _w(norm, ctx), _b(norm, ctx), norm.eps, descr=descr)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, cross_attention_dim):
+        super().__init__()
+        self.norm1 = Norm(dim, 1e-5)
+        self.attn1 = Attention(dim, heads)
+        self.norm2 = Norm(dim, 1e-5)
+        self.attn2 = Attention(dim, heads, cross_attention_dim=cross_attention_dim)
+        self.norm3 = Norm(dim, 1e-5)
+        self.ff = FeedForward(dim)
+
+    def emit(self, ctx, h, B, L_, kv, st):
+        p1, p2 = self.attn1.processor, self.attn2.processor
+        if not hasattr(p1, "emit") or not hasattr(p2, "emit"):
+            raise L.ImhError("a non-HIP attention processor is installed; the fused forward needs "
+                             "imagharmony_amd.attention_processor processors")
+        n = _ln(ctx, self.norm1, h, "norm1")
+        h1 = p1.emit(ctx, self.attn1, n, B, L_, residual=h)
+        ctx.free(n); ctx.free(h)
+        n = _ln(ctx, self.norm2, h1, "norm2")
+        h2 = p2.emit(ctx, self.attn2, n, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab) \
+            if isinstance(p2, IPAttnProcessor2_0) else p2.emit(ctx, self.attn2, n, B, L_, residual=h1, kv=kv)
+        ctx.free(n); ctx.free(h1)
+        n = _ln(ctx, self.norm3, h2, "norm3")
+        h3 = self.ff.emit(ctx, n, residual=h2)
+        ctx.free(n); ctx.free(h2)
+        return h3
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, channels, heads, n_layers, cross_attention_dim, groups):
+        super().__init__()
+        self.norm = Norm(channels, 1e-6)
+        self.groups = groups
+        self.proj_in = Linear(channels, channels)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(channels, heads, cross_attention_dim) for _ in range(n_layers)])
+        self.proj_out = Linear(channels, channels)
+
+    def emit(self, ctx, x, kvs, st):
+        """x: NHWC [B, H, W, C] -> same shape (x is consumed)."""
+        B, Hh, Ww, C_ = x.shape
+        L_ = Hh * Ww
+        x2 = x.view(B * L_, C_)
+        n = ctx.groupnorm(x.view(B, L_, C_), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps,
+                          silu=False, descr="t2d.norm")
+        h = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in")
+        ctx.free(n)
+        for blk, kv in zip(self.transformer_blocks, kvs):
+            h = blk.emit(ctx, h, B, L_, kv, st)
+        out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out")
+        ctx.free(h); ctx.free(x)
+        return out.view(B, Hh, Ww, C_)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups, eps):
+        super().__init__()
+        self.groups = groups
+        self.norm1 = Norm(cin, eps)
+        self.conv1 = Conv2d(cin, cout, 3)
+        self.time_emb_proj = Linear(temb_dim, cout)
+        self.norm2 = Norm(cout, eps)
+        self.conv2 = Conv2d(cout, cout, 3)
+        self.conv_shortcut = Conv2d(cin, cout, 1) if cin != cout else None
+        self.temb_offset = 0    # column of this block inside the stacked time_emb_proj output
+
+    def emit(self, ctx, x, st, keep_input=False):
+        """x: NHWC [B, H, W, Cin] -> [B, H, W, Cout]; x is consumed unless keep_input."""
+        B, Hh, Ww, Cin = x.shape
+        Cout = self.conv1.weight.shape[0]
+        n = ctx.groupnorm(x.view(B, Hh * Ww, Cin), _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups,
+                          self.norm1.eps, silu=True, descr="res.norm1").view(B, Hh, Ww, Cin)
+        ra = st.temb_all[:, self.temb_offset:self.temb_offset + Cout]
+        h = ctx.conv3x3(n, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
+                        descr="res.conv1")
+        ctx.free(n)
+        n = ctx.groupnorm(h.view(B, Hh * Ww, Cout), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups,
+                          self.norm2.eps, silu=True, descr="res.norm2").view(B, Hh, Ww, Cout)
+        ctx.free(h)
+        if self.conv_shortcut is not None:
+            sc = ctx.gemm(x.view(B * Hh * Ww, Cin), self.conv_shortcut.packed(ctx), bias=_b(self.conv_shortcut, ctx),
+                          descr="res.shortcut")
+        else:
+            sc = x.view(B * Hh * Ww, Cin)
+        out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2")
+        ctx.free(n)
+        if self.conv_shortcut is not None:
+            ctx.free(sc)
+        if not keep_input:
+            ctx.free(x)
+        return out
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = Conv2d(c, c, 3)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = Conv2d(c, c, 3)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, n_res, n_tf, heads, cfg, add_down):
+        super().__init__()
+        if n_tf:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, heads, n_tf, cfg.cross_attention_dim, cfg.norm_num_groups)
+                 for _ in range(n_res)])
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps)
+             for i in range(n_res)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
+        self.has_attn = bool(n_tf)
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, n_tf, heads, cfg):
+        super().__init__()
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, n_tf, cfg.cross_attention_dim,
+                                                            cfg.norm_num_groups)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps)
+                                      for _ in range(2)])
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, cprev, n_res, n_tf, heads, cfg, add_up):
+        super().__init__()
+        if n_tf:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, heads, n_tf, cfg.cross_attention_dim, cfg.norm_num_groups)
+                 for _ in range(n_res)])
+        res = []
+        for i in range(n_res):
+            skip = cin if i == n_res - 1 else cout
+            rin = cprev if i == 0 else cout
+            res.append(ResnetBlock2D(rin + skip, cout, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps))
+        self.resnets = nn.ModuleList(res)
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
+        self.has_attn = bool(n_tf)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = Linear(in_dim, dim)
+        self.linear_2 = Linear(dim, dim)
+
+
+class StepState:
+    """Device-resident per-image / per-step state the recorded forward reads."""
+
+    def __init__(self):
+        self.latents = None        # fp32 [S, 4, H, W] (NCHW) -- scheduler state
+        self.t_table = None        # fp32 [steps] timesteps
+        self.step = None           # int32 [1] device step counter
+        self.in_scale_tab = None   # fp32 [steps] scale_model_input factor (Euler) or None
+        self.ip_scale_tab = None   # fp32 [steps] IP scale per step (control_guidance gating) or None
+        self.aug_emb = None        # [B, time_embed_dim]  add_embedding(text_embeds ++ time_ids) (step-invariant)
+        self.kv = None             # {attn2 processor name: KVCache}
+        self.temb_all = None       # [B, sum Cout] stacked time_emb_proj output (per step)
+        self.t_value = None        # fp32 [B] explicit timestep values (eager forward)
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, cfg: UNetConfig = None):
+        super().__init__()
+        cfg = cfg or UNetConfig()
+        self.config = cfg
+        boc = cfg.block_out_channels
+        nb = len(boc)
+        self.conv_in = Conv2d(cfg.in_channels, boc[0], 3)
+        self.time_embedding = TimestepEmbedding(boc[0], cfg.time_embed_dim)
+        self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, cfg.time_embed_dim)
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])     # created before mid_block: fixes the attn_processors order
+        out = boc[0]
+        for i in range(nb):
+            cin, out = out, boc[i]
+            n_tf = 0 if i == 0 else cfg.transformer_layers_per_block[i]
+            self.down_blocks.append(DownBlock(cin, out, cfg.layers_per_block, n_tf, cfg.attention_head_dim[i], cfg,
+                                              add_down=(i != nb - 1)))
+        self.mid_block = MidBlock(boc[-1], cfg.transformer_layers_per_block[-1], cfg.attention_head_dim[-1], cfg)
+        rev, rev_tf = list(reversed(boc)), list(reversed(cfg.transformer_layers_per_block))
+        rev_heads = list(reversed(cfg.attention_head_dim))
+        out = rev[0]
+        for i in range(nb):
+            prev, out = out, rev[i]
+            cin = rev[min(i + 1, nb - 1)]
+            n_tf = 0 if i == nb - 1 else rev_tf[i]
+            self.up_blocks.append(UpBlock(cin, out, prev, cfg.layers_per_block + 1, n_tf, rev_heads[i], cfg,
+                                          add_up=(i != nb - 1)))
+        self.conv_norm_out = Norm(boc[0], cfg.norm_eps)
+        self.conv_out = Conv2d(boc[0], cfg.out_channels, 3)
+        # stacked time_emb_proj bookkeeping
+        off = 0
+        for r in self.resnets():
+            r.temb_offset = off
+            off += r.time_emb_proj.weight.shape[0]
+        self.temb_total = off
+
+    # ---- iteration helpers ----
+    def resnets(self):
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            for r in blk.resnets:
+                yield r
+
+    # ---- processor protocol (ip_adapter/ip_adapter.py:102,125) ----
+    @property
+    def attn_processors(self) -> Dict[str, object]:
+        procs = {}
+
+        def rec(name, mod):
+            if hasattr(mod, "get_processor"):
+                procs[f"{name}.processor"] = mod.get_processor()
+            for sub, child in mod.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, child in self.named_children():
+            rec(name, child)
+        return procs
+
+    def set_attn_processor(self, processor):
+        count = len(self.attn_processors)
+        if isinstance(processor, dict) and len(processor) != count:
+            raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} "
+                             f"does not match the number of attention layers: {count}.")
+        if isinstance(processor, dict):
+            processor = dict(processor)
+
+        def rec(name, mod):
+            if hasattr(mod, "set_processor"):
+                mod.set_processor(processor if not isinstance(processor, dict) else processor.pop(f"{name}.processor"))
+            for sub, child in mod.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, child in self.named_children():
+            rec(name, child)
+
+    def attn2_modules(self):
+        """[(processor name, Attention)] for the cross-attention layers, in attn_processors order."""
+        out = []
+
+        def rec(name, mod):
+            if isinstance(mod, Attention) and name.endswith("attn2"):
+                out.append((f"{name}.processor", mod))
+            for sub, child in mod.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, child in self.named_children():
+            rec(name, child)
+        return out
+
+    # ---- random init directly on the device (synthetic-weight benchmarks) ----
+    @torch.no_grad()
+    def init_random_(self, seed=1234):
+        g = torch.Generator(device=self.conv_in.weight.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if p.ndim >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32).mul_(fan_in ** -0.5))
+            elif name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32).mul_(0.02))
+            else:
+                p.fill_(1.0)
+        return self
+
+    # ---- packed / stacked weights ----
+    def _temb_stack(self, ctx):
+        key = (ctx.dtype, str(ctx.device))
+        c = getattr(self, "_imh_temb", None)
+        if c is None or c[0] != key:
+            w = torch.cat([r.time_emb_proj.weight.detach() for r in self.resnets()], 0)
+            b = torch.cat([r.time_emb_proj.bias.detach() for r in self.resnets()], 0)
+            c = (key, w.to(device=ctx.device, dtype=ctx.dtype).contiguous(), b.to(device=ctx.device, dtype=ctx.dtype))
+            self._imh_temb = c
+        return c[1], c[2]
+
+    # ---- step-invariant conditioning ----
+    @torch.no_grad()
+    def prepare_conditioning(self, ctx, encoder_hidden_states, text_embeds, time_ids, st=None):
+        """aug_emb = add_embedding(cat[text_embeds, Timesteps(256)(time_ids)]) and the K/V cache of every
+        cross-attention layer (all independent of the denoise step)."""
+        st = st or StepState()
+        cfg = self.config
+        B = encoder_hidden_states.shape[0]
+        ids = time_ids.to(device=ctx.device, dtype=torch.float32).reshape(-1).contiguous()
+        te = ctx.new(ids.numel(), cfg.addition_time_embed_dim)
+        ctx.ew(L.EW_TIMESTEP, te, a=ids, n=ids.numel(), i=(cfg.addition_time_embed_dim, 0, 0, 0, 0, 0),
+               descr="add_time_proj")
+        add_in = torch.cat([text_embeds.to(device=ctx.device, dtype=ctx.dtype), te.view(B, -1)], dim=-1).contiguous()
+        ae = self.add_embedding
+        h = ctx.gemm(add_in, _w(ae.linear_1, ctx), bias=_b(ae.linear_1, ctx), flags=L.GF_ACT_SILU, descr="add_emb.1")
+        st.aug_emb = ctx.gemm(h, _w(ae.linear_2, ctx), bias=_b(ae.linear_2, ctx), descr="add_emb.2")
+        ehs = encoder_hidden_states.to(device=ctx.device, dtype=ctx.dtype)
+        st.kv = {}
+        for name, attn in self.attn2_modules():
+            proc = attn.processor
+            if not hasattr(proc, "prepare_kv"):
+                raise L.ImhError(f"{name}: processor {type(proc).__name__} has no HIP K/V path")
+            st.kv[name] = proc.prepare_kv(ctx, attn, ehs)
+        if ctx.record:
+            ctx.keep.extend([ids, add_in, ehs])
+        return st
+
+    # ---- the forward, as emitted ops ----
+    def emit_forward(self, ctx, st, S, Hl, Wl, cfg_dup=True):
+        """Records one UNet forward.  Reads st.latents (fp32 NCHW [S,4,Hl,Wl]); batch B = 2S when
+        cfg_dup (CFG halves share the latent, custom_pipelines.py:332).  Returns the noise prediction
+        as NHWC [B, Hl*Wl, 4] in the compute dtype."""
+        cfg = self.config
+        B = 2 * S if cfg_dup else S
+        boc = cfg.block_out_channels
+        # -- time embedding --
+        ctx.tag = 1
+        tsin = ctx.new(B, boc[0])
+        if st.t_table is not None:
+            ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_table, step=st.step, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
+        else:
+            ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_value, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
+        te = self.time_embedding
+        h = ctx.gemm(tsin, _w(te.linear_1, ctx), bias=_b(te.linear_1, ctx), flags=L.GF_ACT_SILU, descr="time_emb.1")
+        # emb = time_embedding(t) + aug_emb, then SiLU (every ResnetBlock2D applies it before time_emb_proj)
+        emb = ctx.gemm(h, _w(te.linear_2, ctx), bias=_b(te.linear_2, ctx), residual=st.aug_emb, descr="time_emb.2")
+        semb = ctx.silu(emb, descr="silu(emb)")
+        wt, bt = self._temb_stack(ctx)
+        st.temb_all = ctx.gemm(semb, wt, bias=bt, descr="time_emb_proj(all)")
+        ctx.free(tsin); ctx.free(h); ctx.free(emb); ctx.free(semb)
+        # -- conv_in (+ CFG duplication + scale_model_input) --
+        ctx.tag = 2
+        x = ctx.new(B, Hl, Wl, boc[0])
+        ctx.ew(L.EW_CONV_IN, x, a=st.latents, w=_w(self.conv_in, ctx), bias=_b(self.conv_in, ctx),
+               tab=st.in_scale_tab, step=st.step if st.in_scale_tab is not None else None,
+               i=(S, Hl, Wl, boc[0], B, 0), f=(1.0, 0, 0, 0), descr="conv_in",
+               nbytes=2.0 * B * Hl * Wl * boc[0])
+        skips = [x]
+        h = x
+        # -- down --
+        for bi, blk in enumerate(self.down_blocks):
+            for i, r in enumerate(blk.resnets):
+                ctx.tag = 10 + bi
+                h = r.emit(ctx, h, st, keep_input=True)      # inputs are skip tensors: keep
+                if blk.has_attn:
+                    ctx.tag = 20 + bi
+                    t2d = blk.attentions[i]
+                    kvs = [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))]
+                    hin = h
+                    h = self._t2d_keep(ctx, t2d, hin, kvs, st)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                ctx.tag = 10 + bi
+                d = blk.downsamplers[0].conv
+                h = ctx.conv3x3(h, d.packed(ctx), bias=_b(d, ctx), stride=2, descr="downsample")
+                skips.append(h)
+        # -- mid --
+        ctx.tag = 30
+        mb = self.mid_block
+        h = mb.resnets[0].emit(ctx, h, st, keep_input=True)
+        t2d = mb.attentions[0]
+        ctx.tag = 31
+        h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st)
+        ctx.tag = 30
+        h = mb.resnets[1].emit(ctx, h, st)
+        # -- up --
+        for bi, blk in enumerate(self.up_blocks):
+            for i, r in enumerate(blk.resnets):
+                ctx.tag = 40 + bi
+                sk = skips.pop()
+                hc = ctx.concat(h, sk, descr="skip.concat")
+                ctx.free(h); ctx.free(sk)
+                h = r.emit(ctx, hc, st)
+                if blk.has_attn:
+                    ctx.tag = 50 + bi
+                    t2d = blk.attentions[i]
+                    h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st)
+            if blk.upsamplers is not None:
+                ctx.tag = 40 + bi
+                u = blk.upsamplers[0].conv
+                hu = ctx.conv3x3(h, u.packed(ctx), bias=_b(u, ctx), up=1, descr="upsample")
+                ctx.free(h)
+                h = hu
+        # -- out --
+        ctx.tag = 60
+        Bh, Hh, Ww, C0 = h.shape
+        n = ctx.groupnorm(h.view(B, Hh * Ww, C0), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx),
+                          cfg.norm_num_groups, cfg.norm_eps, silu=True, descr="conv_norm_out").view(B, Hh, Ww, C0)
+        ctx.free(h)
+        out = ctx.conv3x3(n, self.conv_out.packed(ctx), bias=_b(self.conv_out, ctx), descr="conv_out")
+        ctx.free(n)
+        ctx.tag = 0
+        return out.view(B, Hh * Ww, cfg.out_channels)
+
+    def _t2d_keep(self, ctx, t2d, x, kvs, st):
+        """Transformer2DModel whose input is NOT a skip tensor owner: Transformer2DModel.emit consumes x."""
+        return t2d.emit(ctx, x, kvs, st)
+
+    def _pname(self, t2d, k):
+        names = getattr(self, "_imh_pnames", None)
+        if names is None:
+            names = {}
+            for name, mod in self.named_modules():
+                if isinstance(mod, Attention) and name.endswith("attn2"):
+                    names[id(mod)] = f"{name}.processor"
+            self._imh_pnames = names
+        return names[id(t2d.transformer_blocks[k].attn2)]
+
+    # ---- eager drop-in signature (diffusers UNet2DConditionModel.forward) ----
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, cross_attention_kwargs=None,
+                return_dict=False, **kw):
+        dev = sample.device
+        dtype = self.conv_in.weight.dtype if self.conv_in.weight.dtype in (torch.bfloat16, torch.float16) \
+            else (sample.dtype if sample.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16)
+        ctx = Ctx(dev, dtype)
+        B, _, Hl, Wl = sample.shape
+        st = self.prepare_conditioning(ctx, encoder_hidden_states, added_cond_kwargs["text_embeds"],
+                                       added_cond_kwargs["time_ids"])
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
+        st.t_value = t.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        st.latents = sample.to(torch.float32).contiguous()
+        out = self.emit_forward(ctx, st, B, Hl, Wl, cfg_dup=False)
+        y = out.view(B, Hl, Wl, -1).permute(0, 3, 1, 2).to(sample.dtype)
+        return (y,)

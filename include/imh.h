@@ -1,0 +1,211 @@
+/*
+ * libimh_hip.so -- C ABI of the MI355X (gfx950) kernels behind the IMAGHarmony SDXL
+ * denoising hot path.
+ *
+ * The reference (muzishen/IMAGHarmony) is pure Python and has no FFI of its own; every GPU
+ * kernel it runs comes from PyTorch through diffusers.  The entry points below are what a
+ * Python binding of THIS path binds with ctypes (INTEGRATION.md shows the stub); each one
+ * cites the reference call sites whose arithmetic it replaces.
+ *
+ * Contract
+ *   - plain C: raw device pointers, ints, floats; no torch / C++ types in any signature.
+ *   - ownership: the caller owns every buffer (activations, weights, workspaces).  Kernels
+ *     never allocate or free; workspace sizes are queried with *_workspace_bytes().
+ *   - all work is enqueued on the caller's stream (hipStream_t passed as void*); no internal
+ *     synchronisation, no malloc/free -> every entry point is hipGraph-capturable.
+ *   - errors: 0 (IMH_OK) or a negative imh_status; imh_last_error() returns a thread-local
+ *     message.  Nothing throws across the ABI, nothing calls exit().
+ *   - stateless and re-entrant (plans are explicit handles owned by the caller).
+ *   - dtype: IMH_DT_BF16 / IMH_DT_F16 activations+weights, fp32 accumulation everywhere.
+ *   - layouts: activations are token-major / NHWC ([B, H*W, C] row-major); weights are
+ *     [out, in] row-major exactly as torch.nn.Linear stores them; conv3x3 weights are
+ *     pre-packed to [Cout][ky][kx][Cin] (imagharmony_amd.packing).
+ */
+#ifndef IMH_H_
+#define IMH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMH_ABI_VERSION 1
+
+enum imh_status {
+    IMH_OK = 0,
+    IMH_ERR_ARG = -1,
+    IMH_ERR_SHAPE = -2,
+    IMH_ERR_DTYPE = -3,
+    IMH_ERR_LAUNCH = -4,
+    IMH_ERR_WORKSPACE = -5
+};
+
+enum imh_dtype { IMH_DT_BF16 = 0, IMH_DT_F16 = 1 };
+
+/* epilogue flags of imh_gemm_args.flags */
+enum imh_gemm_flags {
+    IMH_GF_GEGLU = 1,     /* columns interleaved (value, gate); out[n/2] = a * gelu(g)  (diffusers GEGLU) */
+    IMH_GF_ACT_GELU = 2,  /* exact-erf GELU (resampler.py:18) */
+    IMH_GF_ACT_SILU = 4,  /* SiLU (TimestepEmbedding) */
+    IMH_GF_VT_PERM = 8,   /* write the attention V^T key permutation (see imh_attention) */
+    IMH_GF_OUT_F32 = 16   /* fp32 output */
+};
+
+/* ---- dense contraction ------------------------------------------------------------------
+ * Y[m, n] = epilogue( sum_k X[m, k] * W[n, k] ),  epilogue = (+bias[n]) (+rowadd[m / rows_per_batch, n])
+ *           (act) (GEGLU) (+residual[m, n]).
+ * conv == 0: torch.nn.Linear.  Replaces attn.to_q/to_k/to_v/to_out[0] and to_k_ip/to_v_ip
+ *   (ip_adapter/attention_processor.py:292,299,300,320,396,410,411,432,433,453), diffusers
+ *   proj_in/proj_out/FeedForward/TimestepEmbedding/time_emb_proj/conv_shortcut,
+ *   Resampler / ImageProjModel / HarmonyAttention linears (resampler.py:13-20,45-47,101-103;
+ *   ip_adapter.py:38; train.py:208,239).
+ * conv == 1: 3x3 convolution, padding 1, stride 1|2, optional fused nearest x2 upsampling of the
+ *   input (up = 1), as an implicit GEMM over NHWC input [B, H, Wd, Cin]; K = 9*Cin; M = B*Ho*Wo.
+ *   Replaces diffusers ResnetBlock2D.conv1/conv2, Downsample2D.conv, Upsample2D(+interpolate), conv_out.
+ * K must be a multiple of 64; M and N are arbitrary (edge tiles read a zero page).
+ * bm/bn/splits = 0 selects the built-in heuristic.  splits > 1 needs `partial`
+ * (imh_gemm_workspace_bytes) and runs a second reduce+epilogue kernel.
+ */
+typedef struct imh_gemm_args {
+    const void* X;
+    const void* W;
+    void* Y;
+    float* partial;
+    const void* bias;
+    const void* rowadd;
+    const void* residual;
+    int32_t M, N, K;
+    int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
+    int32_t rows_per_batch;
+    int32_t splits;
+    int32_t flags;
+    int32_t H, Wd, Cin, Ho, Wo, stride, up;
+    int32_t dtype;
+    int32_t conv;
+    int32_t bm, bn;
+} imh_gemm_args;
+
+int imh_gemm(const imh_gemm_args* a, void* stream);
+int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
+size_t imh_gemm_workspace_bytes(int M, int N, int splits);
+
+/* ---- attention, head_dim 64 -------------------------------------------------------------
+ * O[b, q, h*64:(h+1)*64] = softmax(Q K^T * scale) V  (+ scale2 * softmax(Q K2^T * scale) V2)
+ * Replaces F.scaled_dot_product_attention in AttnProcessor2_0 (attention_processor.py:312) and both
+ * SDPA calls + the axpy of IPAttnProcessor2_0 (:423-425, :440-442, :450).
+ *   Q  : [B, Lq, ldq], head h at columns h*64..
+ *   K  : [B, Lk_pad, ldk] (rows >= Lk are padding and must be finite), head h at columns h*64..
+ *   Vt : [H*64, ldvt] = V transposed; batch b occupies columns b*Lk_pad .. ; inside every group of
+ *        16 keys the order is [0-3, 8-11, 4-7, 12-15] (what imh_gemm writes with IMH_GF_VT_PERM);
+ *        padding columns must be finite (zero).
+ *   K2/Vt2 (optional): the image-prompt key set of the IP branch, same layouts.
+ * Lk_pad, Lk2_pad multiples of 64.
+ */
+typedef struct imh_attn_args {
+    const void* Q;
+    const void* K;
+    const void* Vt;
+    const void* K2;
+    const void* Vt2;
+    void* O;
+    int32_t B, H, Lq;
+    int32_t Lk, Lk_pad;
+    int32_t Lk2, Lk2_pad;
+    int32_t ldq, ldk, ldvt, ldk2, ldvt2, ldo;
+    float scale;
+    float scale2;
+    const float* scale2_tab; /* optional: scale2 = scale2_tab[*step] (per-step IP-scale gating,
+                                custom_pipelines.py:326-329, without re-recording the plan) */
+    const int32_t* step;
+    int32_t dtype;
+} imh_attn_args;
+
+int imh_attention(const imh_attn_args* a, void* stream);
+
+/* ---- normalisation ----------------------------------------------------------------------
+ * imh_groupnorm: GroupNorm(groups) over NHWC x[B, HW, C] with optional fused SiLU
+ *   (diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out).
+ * imh_layernorm: LayerNorm over the last dim of x[rows, C] (BasicTransformerBlock.norm1/2/3,
+ *   ip_adapter.py:39, resampler.py:15,42,43,104, train.py:238).  gamma/beta may be NULL.
+ */
+typedef struct imh_norm_args {
+    const void* x;
+    void* y;
+    const void* gamma;
+    const void* beta;
+    float* partial;
+    int32_t B, HW, C, groups;
+    int32_t rows;
+    float eps;
+    int32_t silu;
+    int32_t dtype;
+} imh_norm_args;
+
+int imh_groupnorm(const imh_norm_args* a, void* stream);
+size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int imh_layernorm(const imh_norm_args* a, void* stream);
+
+/* ---- small fused elementwise kernels (see csrc/elementwise.hip for the field meaning) ---- */
+enum imh_ew_op {
+    IMH_EW_TIMESTEP = 0,  /* diffusers Timesteps() sinusoid */
+    IMH_EW_SILU = 1,
+    IMH_EW_CONCAT = 2,    /* NHWC channel concat (up-block skips) */
+    IMH_EW_CONV_IN = 3,   /* conv_in + CFG duplication (custom_pipelines.py:332) + scale_model_input (:334) */
+    IMH_EW_CFG_STEP = 4,  /* CFG combine (:348-350) + scheduler.step (:357) */
+    IMH_EW_CAST_F32 = 5,
+    IMH_EW_ADD = 6,
+    IMH_EW_STEP_SET = 7   /* *y(int32) = i1 ? i0 : *y + 1 : the device-side step counter */
+};
+
+typedef struct imh_ew_args {
+    const void* a;
+    const void* b;
+    void* y;
+    const void* w;
+    const void* bias;
+    const float* tab;      /* optional per-step scalar table, indexed by *step */
+    const int32_t* step;   /* device-resident denoise-step counter */
+    int64_t n;
+    int32_t i0, i1, i2, i3, i4, i5;
+    float f0, f1, f2, f3;
+    int32_t dtype;
+} imh_ew_args;
+
+int imh_elementwise(int op, const imh_ew_args* a, void* stream);
+
+/* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
+ * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
+enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4 };
+
+typedef struct imh_plan imh_plan;
+
+imh_plan* imh_plan_create(void);
+void imh_plan_destroy(imh_plan* p);
+/* args points to the matching *_args struct (copied); ew_op only for IMH_OP_EW; tag is a small
+ * caller-defined integer carried for profiling (e.g. which layer family). Returns op index or <0. */
+int imh_plan_add(imh_plan* p, int kind, const void* args, int ew_op, int tag);
+int imh_plan_size(const imh_plan* p);
+/* in-place update of one recorded op's argument struct (per-step scalars such as the scheduler
+ * coefficients); invalidates a captured graph. */
+int imh_plan_update(imh_plan* p, int index, const void* args);
+int imh_plan_run(imh_plan* p, void* stream);
+/* run ops [first, last) */
+int imh_plan_run_range(imh_plan* p, int first, int last, void* stream);
+/* capture the whole plan into a hipGraph on `stream` (which must be a non-default stream) */
+int imh_plan_capture(imh_plan* p, void* stream);
+int imh_plan_replay(imh_plan* p, void* stream);
+/* run once with a hipEvent pair around every op on `stream`; ms[i] receives op i's duration.
+ * Synchronises the stream (measurement helper, not capturable). */
+int imh_plan_time_ops(imh_plan* p, void* stream, float* ms, int n);
+int imh_plan_get_tag(const imh_plan* p, int index);
+int imh_plan_get_kind(const imh_plan* p, int index);
+
+const char* imh_last_error(void);
+int imh_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMH_H_ */

@@ -1,0 +1,314 @@
+"""GPU parity of every HIP kernel behind the C ABI against a plain fp32 PyTorch statement of the
+same op (run with ``pytest -m gpu`` on an MI355X).  Tolerances: outputs are bf16/fp16 with fp32
+accumulation; the bound used is a few output-dtype ulps of the result scale (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.bfloat16, torch.float16]
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from imagharmony_amd import lib
+    lib.load()
+    return lib
+
+
+def ctx_for(dtype):
+    from imagharmony_amd.ctx import Ctx
+    return Ctx(DEV, dtype)
+
+
+def rnd(*shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def assert_close(y, ref, dtype, what, k=4.0):
+    ref = ref.float()
+    y = y.float()
+    scale = ref.abs().max().item() + 1e-6
+    err = (y - ref).abs().max().item()
+    rms = ((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12)).item()
+    assert math.isfinite(err), f"{what}: non-finite output"
+    assert err <= k * EPS[dtype] * scale and rms <= 2 * EPS[dtype], f"{what}: max err {err:.3e} (scale {scale:.3e}), rel-rms {rms:.3e}"
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(128, 128, 1), (128, 64, 1), (64, 128, 1), (64, 64, 1), (128, 128, 2), (64, 64, 4)])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 200, 192), (64, 1280, 640), (2, 320, 64), (130, 72, 64)])
+def test_gemm_plain(L, dtype, cfg, shape):
+    M, N, K = shape
+    ctx = ctx_for(dtype)
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    y = ctx.gemm(x, w, cfg=cfg)
+    assert_close(y, x.float() @ w.float().t(), dtype, f"gemm {shape} {cfg}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(L, dtype):
+    ctx = ctx_for(dtype)
+    M, N, K = 192, 256, 128
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b, r = rnd(N, dtype=dtype, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    ref = x.float() @ w.float().t()
+    assert_close(ctx.gemm(x, w, bias=b), ref + b.float(), dtype, "bias")
+    assert_close(ctx.gemm(x, w, bias=b, residual=r), ref + b.float() + r.float(), dtype, "bias+residual")
+    assert_close(ctx.gemm(x, w, bias=b, flags=L.GF_ACT_SILU), F.silu(ref + b.float()), dtype, "silu")
+    assert_close(ctx.gemm(x, w, flags=L.GF_ACT_GELU), F.gelu(ref), dtype, "gelu")
+    # rowadd: 3 batches of 64 rows, row stride larger than N (stacked time_emb_proj layout)
+    ra_full = rnd(3, N + 64, dtype=dtype, seed=5)
+    ra = ra_full[:, 32:32 + N]
+    y = ctx.gemm(x, w, bias=b, rowadd=ra, rows_per_batch=64, ldra=ra_full.stride(0))
+    assert_close(y, ref + b.float() + ra.float().repeat_interleave(64, 0), dtype, "rowadd")
+    # split-K with every epilogue
+    y = ctx.gemm(x, w, bias=b, residual=r, cfg=(64, 64, 2))
+    assert_close(y, ref + b.float() + r.float(), dtype, "splitk epilogue")
+    # fp32 output
+    y = ctx.gemm(x, w, flags=L.GF_OUT_F32)
+    assert y.dtype == torch.float32
+    assert_close(y, ref, dtype, "f32 out")
+    # strided operands (column slices)
+    xb = rnd(M, K + 64, dtype=dtype, seed=6)
+    y = ctx.gemm(xb[:, 64:], w)
+    assert_close(y, xb[:, 64:].float() @ w.float().t(), dtype, "strided x")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(128, 128, 1), (64, 64, 1), (128, 64, 2)])
+def test_gemm_geglu(L, dtype, cfg):
+    ctx = ctx_for(dtype)
+    M, K, inner = 160, 128, 256
+    x = rnd(M, K, dtype=dtype, seed=1)
+    w, b = rnd(2 * inner, K, dtype=dtype, seed=2, scale=K ** -0.5), rnd(2 * inner, dtype=dtype, seed=3)
+    r = rnd(M, inner, dtype=dtype, seed=4)
+    wi = torch.stack([w[:inner], w[inner:]], 1).reshape(2 * inner, K).contiguous()
+    bi = torch.stack([b[:inner], b[inner:]], 1).reshape(2 * inner).contiguous()
+    y = ctx.gemm(x, wi, bias=bi, flags=L.GF_GEGLU, residual=r, cfg=cfg)
+    full = x.float() @ w.float().t() + b.float()
+    ref = full[:, :inner] * F.gelu(full[:, inner:]) + r.float()
+    assert y.shape == (M, inner)
+    assert_close(y, ref, dtype, f"geglu {cfg}")
+
+
+def vt_unpermute(vt):
+    """[C, n] with 16-groups stored as [0-3, 8-11, 4-7, 12-15] -> logical order"""
+    C_, n = vt.shape
+    v = vt.view(C_, n // 16, 4, 4)
+    return v[:, :, [0, 2, 1, 3], :].reshape(C_, n)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(128, 128, 1), (64, 128, 1), (64, 64, 2)])
+def test_gemm_vt_perm(L, dtype, cfg):
+    ctx = ctx_for(dtype)
+    C_, n, K = 128, 192, 64
+    wv, x = rnd(C_, K, dtype=dtype, seed=1, scale=K ** -0.5), rnd(n, K, dtype=dtype, seed=2)
+    vt = ctx.gemm(wv, x, flags=L.GF_VT_PERM, cfg=cfg)
+    assert_close(vt_unpermute(vt), wv.float() @ x.float().t(), dtype, "V^T")
+
+
+# ------------------------------------------------------------------------------------ conv
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(B=2, H=16, W=16, Cin=64, Cout=128), dict(B=1, H=12, W=20, Cin=128, Cout=64),
+                                  dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2), dict(B=2, H=8, W=8, Cin=64, Cout=64, up=1),
+                                  dict(B=2, H=8, W=8, Cin=192, Cout=4), dict(B=1, H=32, W=32, Cin=320, Cout=320, cfg=(128, 128, 2))])
+def test_conv3x3(L, dtype, case):
+    ctx = ctx_for(dtype)
+    B, H, W, Cin, Cout = case["B"], case["H"], case["W"], case["Cin"], case["Cout"]
+    stride, up = case.get("stride", 1), case.get("up", 0)
+    x = rnd(B, H, W, Cin, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, dtype=dtype, seed=3)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    temb = rnd(B, Cout, dtype=dtype, seed=4)
+    res = rnd(*ref.shape, dtype=dtype, seed=5)
+    y = ctx.conv3x3(x, wp, bias=b, stride=stride, up=up, rowadd=temb, residual=res.view(-1, Cout), cfg=case.get("cfg"))
+    assert y.shape == ref.shape
+    assert_close(y, ref + temb.float()[:, None, None, :] + res.float(), dtype, f"conv {case}")
+
+
+# ------------------------------------------------------------------------------------ attention
+def make_vt(v, n_pad):
+    """v [B, n, H*64] -> permuted V^T [H*64, B*n_pad]"""
+    B, n, C_ = v.shape
+    vp = torch.zeros(B, n_pad, C_, dtype=v.dtype, device=v.device)
+    vp[:, :n] = v
+    vt = vp.permute(2, 0, 1).reshape(C_, B * n_pad // 16, 4, 4)
+    return vt[:, :, [0, 2, 1, 3], :].reshape(C_, B * n_pad).contiguous()
+
+
+def sdpa_ref(q, k, v, H):
+    B, Lq, C_ = q.shape
+    hs = lambda t: t.float().view(B, -1, H, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(hs(q), hs(k), hs(v))
+    return o.transpose(1, 2).reshape(B, Lq, C_)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192)])
+def test_attention_self(L, dtype, B, H, Lq):
+    ctx = ctx_for(dtype)
+    C_ = H * 64
+    qk = rnd(B * Lq, 2 * C_, dtype=dtype, seed=1)
+    v = rnd(B, Lq, C_, dtype=dtype, seed=2)
+    vt = make_vt(v, Lq)
+    out = ctx.new(B * Lq, C_)
+    ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125)
+    ref = sdpa_ref(qk[:, :C_].reshape(B, Lq, C_), qk[:, C_:].reshape(B, Lq, C_), v, H)
+    assert_close(out.view(B, Lq, C_), ref, dtype, "self attention", k=6.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,nt,nip", [(2, 2, 256, 77, 4), (1, 20, 128, 77, 16), (2, 1, 100, 77, 32), (1, 2, 64, 130, 0)])
+def test_attention_cross_ip(L, dtype, B, H, Lq, nt, nip):
+    ctx = ctx_for(dtype)
+    C_ = H * 64
+    q = rnd(B * Lq, C_, dtype=dtype, seed=1)
+    k, v = rnd(B, nt, C_, dtype=dtype, seed=2), rnd(B, nt, C_, dtype=dtype, seed=3)
+    pad = lambda n: (n + 63) // 64 * 64
+    kp = torch.zeros(B, pad(nt), C_, dtype=dtype, device=DEV)
+    kp[:, :nt] = k
+    out = ctx.new(B * Lq, C_)
+    ref = sdpa_ref(q.view(B, Lq, C_), k, v, H)
+    kw = {}
+    if nip:
+        k2, v2 = rnd(B, nip, C_, dtype=dtype, seed=4), rnd(B, nip, C_, dtype=dtype, seed=5)
+        k2p = torch.zeros(B, pad(nip), C_, dtype=dtype, device=DEV)
+        k2p[:, :nip] = k2
+        kw = dict(k2=k2p, vt2=make_vt(v2, pad(nip)), Lk2=nip, Lk2_pad=pad(nip), ldk2=C_, ldvt2=B * pad(nip), scale2=0.7)
+        ref = ref + 0.7 * sdpa_ref(q.view(B, Lq, C_), k2, v2, H)
+    ctx.attention(q, kp, make_vt(v, pad(nt)), out, B, H, Lq, nt, pad(nt), C_, C_, B * pad(nt), C_, 0.125, **kw)
+    assert_close(out.view(B, Lq, C_), ref, dtype, "cross attention", k=6.0)
+
+
+def test_attention_spiked_scores(L):
+    """forces the online-softmax rescale path: one key dominates late in the sequence"""
+    dtype = torch.bfloat16
+    ctx = ctx_for(dtype)
+    B, H, Lq = 1, 1, 256
+    qk = rnd(B * Lq, 128, dtype=dtype, seed=1)
+    qk[:, 64:][200] = qk[:, :64][7] * 6.0          # key 200 aligned with query 7 -> huge late score
+    v = rnd(B, Lq, 64, dtype=dtype, seed=2)
+    out = ctx.new(B * Lq, 64)
+    ctx.attention(qk[:, :64], qk[:, 64:], make_vt(v, Lq), out, B, H, Lq, Lq, Lq, 128, 128, Lq, 64, 0.125)
+    ref = sdpa_ref(qk[:, :64].reshape(B, Lq, 64), qk[:, 64:].reshape(B, Lq, 64), v, H)
+    assert_close(out.view(B, Lq, 64), ref, dtype, "spiked", k=6.0)
+
+
+# ------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C_,silu", [(2, 256, 320, True), (1, 1024, 64, False), (2, 64, 1280, True), (1, 100, 2560, True),
+                                          (2, 4096, 640, True)])
+def test_groupnorm(L, dtype, B, HW, C_, silu):
+    ctx = ctx_for(dtype)
+    x = rnd(B, HW, C_, dtype=dtype, seed=1) + 0.5
+    g, b = rnd(C_, dtype=dtype, seed=2) * 0.1 + 1, rnd(C_, dtype=dtype, seed=3) * 0.1
+    y = ctx.groupnorm(x, g, b, 32, 1e-5, silu)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, g.float(), b.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert_close(y, ref.transpose(1, 2), dtype, "groupnorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C_", [(100, 640), (64, 1280), (7, 2048), (3, 4096), (5, 64)])
+def test_layernorm(L, dtype, rows, C_):
+    ctx = ctx_for(dtype)
+    x = rnd(rows, C_, dtype=dtype, seed=1) * 2 + 0.3
+    g, b = rnd(C_, dtype=dtype, seed=2) * 0.1 + 1, rnd(C_, dtype=dtype, seed=3) * 0.1
+    y = ctx.layernorm(x, g, b, 1e-5)
+    assert_close(y, F.layer_norm(x.float(), (C_,), g.float(), b.float(), 1e-5), dtype, "layernorm")
+
+
+# ------------------------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(L, dtype):
+    ctx = ctx_for(dtype)
+    # timestep embedding
+    t = torch.tensor([958.0, 1.0, 500.0], device=DEV)
+    y = ctx.new(3, 320)
+    ctx.ew(L.EW_TIMESTEP, y, a=t, n=3, i=(320, 0, 0, 0, 0, 0))
+    half = 160
+    fr = torch.exp(-math.log(10000.0) * torch.arange(half, device=DEV, dtype=torch.float32) / half)
+    a = t[:, None] * fr[None]
+    assert_close(y, torch.cat([a.cos(), a.sin()], -1), dtype, "timestep", k=2.0)
+    # silu + concat
+    x = rnd(64, 128, dtype=dtype, seed=1)
+    assert_close(ctx.silu(x), F.silu(x.float()), dtype, "silu", k=2.0)
+    b = rnd(64, 64, dtype=dtype, seed=2)
+    assert torch.equal(ctx.concat(x, b), torch.cat([x, b], -1))
+    # conv_in with CFG duplication and input scale
+    S, H, W, C0 = 2, 16, 12, 64
+    lat = torch.randn(S, 4, H, W, device=DEV)
+    w, bias = rnd(C0, 4, 3, 3, dtype=dtype, seed=3, scale=1 / 6), rnd(C0, dtype=dtype, seed=4)
+    out = ctx.new(2 * S, H, W, C0)
+    ctx.ew(L.EW_CONV_IN, out, a=lat, w=w, bias=bias, i=(S, H, W, C0, 2 * S, 0), f=(0.5, 0, 0, 0))
+    xin = (lat * 0.5).to(dtype).float()
+    ref = F.conv2d(torch.cat([xin, xin]), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    assert_close(out, ref, dtype, "conv_in")
+    # CFG + scheduler step
+    HW = H * W
+    npred = rnd(2 * S, HW, 4, dtype=dtype, seed=5)
+    lat2 = lat.clone()
+    ctx.ew(L.EW_CFG_STEP, lat2, a=npred, i=(S, HW, 0, 1, 0, 0), f=(0.9, -0.3, 5.0, 0))
+    n = npred.float().view(2, S, HW, 4).permute(0, 1, 3, 2)      # [2, S, 4, HW]
+    eps = n[0] + 5.0 * (n[1] - n[0])
+    ref = 0.9 * lat.view(S, 4, HW) + -0.3 * eps
+    assert (lat2.view(S, 4, HW) - ref).abs().max().item() < 1e-5
+
+
+def test_step_counter_tables(L):
+    dtype = torch.bfloat16
+    ctx = ctx_for(dtype)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ttab = torch.tensor([958.0, 925.0, 892.0], device=DEV)
+    y = ctx.new(2, 64)
+    for i in range(3):
+        ctx.ew(L.EW_TIMESTEP, y, a=ttab, step=step, n=2, i=(64, 0, 0, 0, 0, 0))
+        assert abs(y[0, 0].float().item() - math.cos(ttab[i].item())) < 2 ** -7
+        ctx.ew(L.EW_STEP_SET, step, i=(0, 0, 0, 0, 0, 0))
+    assert step.item() == 3
+    ctx.ew(L.EW_STEP_SET, step, i=(0, 1, 0, 0, 0, 0))
+    assert step.item() == 0
+
+
+# ------------------------------------------------------------------------------------ plans
+def test_plan_record_replay_capture(L):
+    from imagharmony_amd.ctx import Ctx
+    dtype = torch.bfloat16
+    x, w = rnd(256, 128, dtype=dtype, seed=1), rnd(192, 128, dtype=dtype, seed=2, scale=0.1)
+    eager = ctx_for(dtype)
+    ref = eager.layernorm(eager.gemm(x, w), None, None, 1e-5)
+    rec = Ctx(DEV, dtype, record=True)
+    y = rec.layernorm(rec.gemm(x, w), None, None, 1e-5)
+    assert rec.lib.imh_plan_size(rec.plan) == 2
+    rec.run()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    y.zero_()
+    rec.capture()
+    rec.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    ms = rec.time_ops()
+    assert len(ms) == 2 and all(m >= 0 for m in ms)
+
+
+def test_errors_are_reported_not_thrown(L):
+    ctx = ctx_for(torch.bfloat16)
+    x, w = rnd(64, 96, dtype=torch.bfloat16, seed=1), rnd(64, 96, dtype=torch.bfloat16, seed=2)
+    with pytest.raises(L.ImhError, match="multiple of 64"):
+        ctx.gemm(x, w)

@@ -1,0 +1,49 @@
+"""GPU parity of the HIP attention processors (the diffusers AttentionProcessor plug-in boundary)
+against the golden vectors minted from the reference's own IPAttnProcessor2_0 / AttnProcessor2_0
+(tests/golden/attn_*.pt, oracle/gen_golden.py).  Tolerances from SURVEY.md 8c / BASELINE.md 4:
+fp16 rel-RMS <= 2e-3, bf16 <= 1.5e-2 (measured dtype noise of the reference itself: 6e-4 / 4.8e-3)."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_rms
+from oracle.detfill import det_fill
+from oracle.gen_golden import ATTN_CASES, attn_inputs, make_attn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", list(ATTN_CASES))
+def test_ip_processor_matches_reference_golden(case, dtype):
+    from imagharmony_amd.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+    g = torch.load(os.path.join(GOLDEN, f"attn_{case}.pt"))
+    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    hs, ehs = attn_inputs(case)
+    hs, ehs = hs.to(DEV, dtype), ehs.to(DEV, dtype)
+    attn = make_attn(case, cross=True).to(DEV, dtype)
+    for skip in (False, True):
+        p = det_fill(IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=skip), 17, prefix="proc.").to(DEV, dtype)
+        y = p(attn, hs, encoder_hidden_states=ehs)
+        assert y.shape == hs.shape and y.dtype == dtype
+        r = rel_rms(y.float().cpu(), g[f"ip_skip{int(skip)}"])
+        assert r < TOL[dtype], f"{case} skip={skip}: rel-rms {r:.3e}"
+    sattn = make_attn(case, cross=False).to(DEV, dtype)
+    y = AttnProcessor2_0()(sattn, hs)
+    r = rel_rms(y.float().cpu(), g["self"])
+    assert r < TOL[dtype], f"{case} self: rel-rms {r:.3e}"
+
+
+def test_processor_state_dict_and_surface():
+    """same attribute / state-dict surface as the reference class"""
+    from imagharmony_amd.attention_processor import IPAttnProcessor, IPAttnProcessor2_0
+    p = IPAttnProcessor2_0(640, 2048, scale=0.5, num_tokens=16, skip=True)
+    assert list(p.state_dict().keys()) == ["to_k_ip.weight", "to_v_ip.weight"]
+    assert p.to_k_ip.weight.shape == (640, 2048)
+    assert (p.hidden_size, p.cross_attention_dim, p.scale, p.num_tokens, p.skip) == (640, 2048, 0.5, 16, True)
+    assert IPAttnProcessor is IPAttnProcessor2_0
+    with pytest.raises(TypeError):      # the reference signature takes no extra kwargs (attention_processor.py:364-371)
+        p(None, None, foo=1)

@@ -1,0 +1,120 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/imh.h declares; the
+host-side recording logic (op sequence, buffer lifetimes, FLOP accounting) of the fused UNet
+forward; the lane-level emulator of the kernels' index math.  No compute call is made."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from imagharmony_amd import lib
+    l = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
+    declared = set(re.findall(r"\b(imh_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    bound = {n for n, _, _ in lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for n in declared:
+        assert hasattr(l, n)
+    assert l.imh_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_field_order():
+    from imagharmony_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
+    for cname, struct in (("imh_gemm_args", lib.GemmArgs), ("imh_attn_args", lib.AttnArgs),
+                          ("imh_norm_args", lib.NormArgs), ("imh_ew_args", lib.EwArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.replace("*", " ").split(",")
+            names.append(parts[0].split()[-1])
+            names.extend(p.strip() for p in parts[1:])
+        assert names == [f[0] for f in struct._fields_], cname
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    from imagharmony_amd import lib
+    l = lib.load()
+    a = lib.GemmArgs()
+    assert l.imh_gemm(a, None) == -1 and b"null" in l.imh_last_error()
+    assert l.imh_plan_replay(None, None) == -1
+    p = l.imh_plan_create()
+    assert l.imh_plan_size(p) == 0
+    a.X = a.W = a.Y = 64
+    a.M, a.N, a.K = 8, 8, 64
+    assert l.imh_plan_add(p, lib.OP_GEMM, lib.C.byref(a), 0, 7) == 0
+    assert l.imh_plan_size(p) == 1 and l.imh_plan_get_tag(p, 0) == 7 and l.imh_plan_get_kind(p, 0) == lib.OP_GEMM
+    assert l.imh_plan_add(p, 99, lib.C.byref(a), 0, 0) == -1
+    l.imh_plan_destroy(p)
+    bm, bn, sp = lib.C.c_int(), lib.C.c_int(), lib.C.c_int()
+    assert l.imh_gemm_pick_config(2048, 1280, 11520, lib.C.byref(bm), lib.C.byref(bn), lib.C.byref(sp)) == 0
+    assert bm.value in (64, 128) and bn.value in (64, 128) and sp.value >= 1
+    assert l.imh_gemm_workspace_bytes(100, 200, 4) == 100 * 200 * 4 * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    from imagharmony_amd import lib
+    from imagharmony_amd.ctx import Ctx
+    with pytest.raises(lib.ImhError):
+        Ctx("cpu", torch.bfloat16)
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "imagharmony_amd")):
+        if f.endswith(".py"):
+            src += open(os.path.join(ROOT, "imagharmony_amd", f)).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_emulator_of_kernel_index_math():
+    exe = os.path.join(ROOT, "tests", "emu", "emu_layout")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "emu", "emu_layout.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "FAIL" not in r.stdout
+
+
+def test_unet_recording_dry_run_tiny():
+    """records the whole forward on CPU tensors (never executed): op count, every pool buffer is
+    released exactly once or still owned, processors install through the reference's dict protocol"""
+    from imagharmony_amd.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+    from imagharmony_amd.ctx import Ctx
+    from imagharmony_amd.unet import StepState, UNet2DConditionModel, UNetConfig
+    cfg = UNetConfig(block_out_channels=(64, 128, 256), transformer_layers_per_block=(1, 1, 2),
+                     attention_head_dim=(1, 2, 4), cross_attention_dim=256, addition_time_embed_dim=64,
+                     projection_class_embeddings_input_dim=128 + 6 * 64, sample_size=32)
+    u = UNet2DConditionModel(cfg).to(torch.bfloat16)
+    procs = {}
+    for name in u.attn_processors:                       # ip_adapter/ip_adapter.py:99-125
+        if name.endswith("attn1.processor"):
+            procs[name] = AttnProcessor2_0()
+        else:
+            hidden = 256 if name.startswith("mid_block") else (
+                list(reversed(cfg.block_out_channels))[int(name[len("up_blocks.")])] if name.startswith("up_blocks")
+                else cfg.block_out_channels[int(name[len("down_blocks.")])])
+            procs[name] = IPAttnProcessor2_0(hidden, 256, num_tokens=4,
+                                            skip="down_blocks.2.attentions.1" not in name).to(torch.bfloat16)
+    u.set_attn_processor(procs)
+    assert len(u.attn_processors) == 2 * (2 + 4 + 2 + 6 + 3)
+    ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
+    st = u.prepare_conditioning(ctx, torch.zeros(2, 81, 256), torch.zeros(2, 128), torch.zeros(2, 6))
+    n_prep = ctx.lib.imh_plan_size(ctx.plan)
+    st.t_value = torch.zeros(2)
+    st.latents = torch.zeros(2, 4, 32, 32)
+    out = u.emit_forward(ctx, st, 2, 32, 32, cfg_dup=False)
+    assert out.shape == (2, 32 * 32, 4)
+    n = ctx.lib.imh_plan_size(ctx.plan) - n_prep
+    n_blocks = 2 + 4 + 2 + 6 + 3
+    assert n > 12 * n_blocks
+    kinds = [k for _, k, *_ in ctx.tags]
+    assert kinds.count(1) == n_prep * 0 + 2 * n_blocks          # one self + one cross attention per block
+    with pytest.raises(Exception):
+        ctx.run()
