@@ -72,6 +72,15 @@ static int do_attn(const imh_attn_args* a, hipStream_t s) {
     return attention_launch(p, a->dtype, s);
 }
 
+static int do_attn_small(const imh_small_attn_args* a, hipStream_t s) {
+    if (!a || !a->Q || !a->K || !a->V || !a->O) { set_error("attention_small: null pointer argument"); return IMH_ERR_ARG; }
+    SmallAttnParams p;
+    p.Q = a->Q; p.K = a->K; p.V = a->V; p.O = a->O;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.dq = a->dq; p.dv = a->dv;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.scale = a->scale;
+    return attention_small_launch(p, a->dtype, s);
+}
+
 static NormParams to_norm(const imh_norm_args* a) {
     NormParams p;
     p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.partial = a->partial;
@@ -101,6 +110,7 @@ struct imh_op {
         imh_attn_args attn;
         imh_norm_args norm;
         imh_ew_args ew;
+        imh_small_attn_args sattn;
     } u;
 };
 
@@ -123,6 +133,7 @@ static int run_op(const imh_op& o, hipStream_t s) {
             return layernorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
         }
         case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
+        case IMH_OP_ATTN_SMALL: return do_attn_small(&o.u.sattn, s);
     }
     set_error("plan: unknown op kind %d", o.kind);
     return IMH_ERR_ARG;
@@ -140,6 +151,7 @@ static size_t args_size(int kind) {
         case IMH_OP_GROUPNORM:
         case IMH_OP_LAYERNORM: return sizeof(imh_norm_args);
         case IMH_OP_EW: return sizeof(imh_ew_args);
+        case IMH_OP_ATTN_SMALL: return sizeof(imh_small_attn_args);
     }
     return 0;
 }
@@ -158,6 +170,8 @@ int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 size_t imh_gemm_workspace_bytes(int M, int N, int splits) { return gemm_workspace_bytes(M, N, splits); }
 
 int imh_attention(const imh_attn_args* a, void* stream) { return do_attn(a, (hipStream_t)stream); }
+
+int imh_attention_small(const imh_small_attn_args* a, void* stream) { return do_attn_small(a, (hipStream_t)stream); }
 
 int imh_groupnorm(const imh_norm_args* a, void* stream) {
     if (!a || !a->x || !a->y) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }

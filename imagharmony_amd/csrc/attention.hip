@@ -184,6 +184,65 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 }
 
+// ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
+// Used once per image by HarmonyAttention's Cross_Attention (head_dim 40, value_dim 64, 8 queries x 77 keys;
+// ip_adapter/attention_processor.py:35-56) and by the Resampler's PerceiverAttention (16 queries x 273 keys,
+// fp32 softmax; ip_adapter/resampler.py:66-76).  Latency-bound; not on the per-step path.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p) {
+    extern __shared__ float sm[];            // [Lk] scores, [dq] query row, [8] reductions
+    float* sc = sm;
+    float* qrow = sm + p.Lk;
+    float* red = qrow + p.dq;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int tid = threadIdx.x;
+    const T* Q = (const T*)p.Q + (size_t)b * p.Lq * p.ldq + h * p.dq;
+    const T* K = (const T*)p.K + (size_t)b * p.Lk * p.ldk + h * p.dq;
+    const T* V = (const T*)p.V + (size_t)b * p.Lk * p.ldv + h * p.dv;
+    T* O = (T*)p.O + (size_t)b * p.Lq * p.ldo + h * p.dv;
+    for (int i = 0; i < p.Lq; ++i) {
+        for (int d = tid; d < p.dq; d += 256) qrow[d] = to_f32(Q[(size_t)i * p.ldq + d]);
+        __syncthreads();
+        float mx = -1e30f;
+        for (int k = tid; k < p.Lk; k += 256) {
+            const T* kr = K + (size_t)k * p.ldk;
+            float s = 0.f;
+            for (int d = 0; d < p.dq; ++d) s += qrow[d] * to_f32(kr[d]);
+            s *= p.scale;
+            sc[k] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sum = 0.f;
+        for (int k = tid; k < p.Lk; k += 256) { const float e = __expf(sc[k] - mx); sc[k] = e; sum += e; }
+        sum = wave_sum(sum);
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+        __syncthreads();
+        sum = red[4] + red[5] + red[6] + red[7];
+        for (int d = tid; d < p.dv; d += 256) {
+            float o = 0.f;
+            for (int k = 0; k < p.Lk; ++k) o += sc[k] * to_f32(V[(size_t)k * p.ldv + d]);
+            O[(size_t)i * p.ldo + d] = from_f32<T>(o / sum);
+        }
+        __syncthreads();
+    }
+}
+
+int attention_small_launch(const SmallAttnParams& p, int dtype, hipStream_t stream) {
+    if (p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0 || p.dq <= 0 || p.dv <= 0 || p.Lk > 8192 || p.dq > 1024) {
+        set_error("attention_small: unsupported shape"); return IMH_ERR_SHAPE;
+    }
+    const size_t lds = (size_t)(p.Lk + p.dq + 8) * sizeof(float);
+    dim3 grid(p.B * p.H);
+    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((attn_small_kernel<bf16_t>), grid, dim3(256), lds, stream, p);
+    else if (dtype == IMH_DT_F16) hipLaunchKernelGGL((attn_small_kernel<f16_t>), grid, dim3(256), lds, stream, p);
+    else { set_error("attention_small: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    return check_launch("attn_small_kernel");
+}
+
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     if (p.Lk <= 0 || p.Lk_pad % ATT_KV != 0 || p.Lk_pad < p.Lk) {
         set_error("attention: Lk=%d Lk_pad=%d (pad must be a multiple of 64 and >= Lk)", p.Lk, p.Lk_pad);

@@ -44,6 +44,14 @@ struct AttnParams {
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
 
+struct SmallAttnParams {
+    const void* Q; const void* K; const void* V; void* O;
+    int B, H, Lq, Lk, dq, dv;
+    int ldq, ldk, ldv, ldo;
+    float scale;
+};
+int attention_small_launch(const SmallAttnParams& p, int dtype, hipStream_t stream);
+
 struct NormParams {
     const void* x;
     void* y;

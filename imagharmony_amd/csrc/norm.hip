@@ -7,6 +7,7 @@
 // HarmonyAttention.ln (train.py:238).
 #include "imh_common.h"
 #include "imh_kernels.h"
+#include <algorithm>
 
 namespace imh {
 
@@ -28,15 +29,13 @@ size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p, int nblk) {
     typedef typename Vec<T>::v8 v8;
-    extern __shared__ float lds[];   // [2][C]
+    extern __shared__ float lds[];   // [2][P*C]: per pixel-lane channel sums, reduced in a FIXED order (deterministic)
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
     const int b = blockIdx.y, blk = blockIdx.x;
     const int ppb = (p.HW + nblk - 1) / nblk;
     const int start = blk * ppb, end = min(p.HW, start + ppb);
     const int t = threadIdx.x;
-    for (int i = t; i < 2 * C; i += GN_THREADS) lds[i] = 0.f;
-    __syncthreads();
     if (t < CL * P) {
         const int cl = t % CL, pl = t / CL;
         float s[8], q[8];
@@ -50,15 +49,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(&lds[cl * 8 + e], s[e]);
-            atomicAdd(&lds[C + cl * 8 + e], q[e]);
+            lds[pl * C + cl * 8 + e] = s[e];
+            lds[P * C + pl * C + cl * 8 + e] = q[e];
         }
     }
     __syncthreads();
     if (t < p.groups) {
         const int cpg = C / p.groups;
         float s = 0.f, q = 0.f;
-        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += lds[c]; q += lds[C + c]; }
+        for (int pl = 0; pl < P; ++pl)
+            for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += lds[pl * C + c]; q += lds[P * C + pl * C + c]; }
         float* o = p.partial + (((size_t)b * nblk + blk) * p.groups + t) * 2;
         o[0] = s; o[1] = q;
     }
@@ -128,7 +128,7 @@ int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
     if (!p.partial) { set_error("groupnorm: workspace missing"); return IMH_ERR_WORKSPACE; }
     const int nblk = gn_nblk(p.HW, p.C);
     dim3 grid(nblk, p.B);
-    const size_t lds = 2 * (size_t)p.C * sizeof(float);
+    const size_t lds = 2 * (size_t)p.C * std::max(1, GN_THREADS / (p.C >> 3)) * sizeof(float);
     if (dtype == IMH_DT_BF16) {
         hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
         hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);

@@ -118,6 +118,8 @@ class Ctx:
             rc = self.lib.imh_groupnorm(C.byref(args), s)
         elif kind == L.OP_LAYERNORM:
             rc = self.lib.imh_layernorm(C.byref(args), s)
+        elif kind == L.OP_ATTN_SMALL:
+            rc = self.lib.imh_attention_small(C.byref(args), s)
         else:
             rc = self.lib.imh_elementwise(ew_op, C.byref(args), s)
         L.check(rc, descr or f"op kind {kind}")
@@ -221,6 +223,18 @@ class Ctx:
         fl = 4.0 * B * H * Lq * (Lk + Lk2) * 64
         by = es * (2 * B * Lq * H * 64 + 2 * B * (Lk + Lk2) * H * 64)
         self._emit(L.OP_ATTN, a, descr=descr, flops=fl, nbytes=by, keep=(q, k, vt, out, k2, vt2, scale2_tab, step))
+        return out
+
+    def attention_small(self, q, k, v, B, H, Lq, Lk, dq, dv, scale, out=None, descr="attention_small"):
+        """q [B*Lq, H*dq], k [B*Lk, H*dq], v [B*Lk, H*dv] row-major (any row stride) -> [B*Lq, H*dv]"""
+        if out is None:
+            out = self.new(B * Lq, H * dv)
+        a = L.SmallAttnArgs()
+        a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+        a.B, a.H, a.Lq, a.Lk, a.dq, a.dv = B, H, Lq, Lk, dq, dv
+        a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        a.scale, a.dtype = scale, self.dt
+        self._emit(L.OP_ATTN_SMALL, a, descr=descr, flops=2.0 * B * H * Lq * Lk * (dq + dv), keep=(q, k, v, out))
         return out
 
     # ------------------------------------------------------------------ norms

@@ -1,0 +1,105 @@
+"""The denoise loop of ip_adapter/custom_pipelines.py:249-363 as a device-resident loop.
+
+One denoise step = [UNet forward on the CFG-duplicated latent] + [CFG combine + scheduler.step] +
+[step counter += 1], recorded ONCE into a C++ plan and captured into a hipGraph; the 30-step loop is
+30 graph replays with no host work in between: timesteps, scheduler coefficients, the Euler input
+scale and the per-step IP-scale gate (control_guidance_start/end, custom_pipelines.py:326-329) are
+device tables indexed by a device-resident step counter.
+"""
+import torch
+
+from . import lib as L
+from .ctx import Ctx
+from .unet import StepState
+
+
+class DenoiseEngine:
+    def __init__(self, unet, device, dtype=torch.bfloat16, use_graph=True):
+        self.unet = unet
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.use_graph = use_graph
+        self.eager = Ctx(self.device, dtype)
+        self.st = None
+        self.plan = None
+        self.key = None
+        self.noise_pred = None
+
+    # -- conditioning (once per image / per PNS run; shared by every candidate seed) --
+    @torch.no_grad()
+    def set_conditioning(self, prompt_embeds, negative_prompt_embeds, pooled, negative_pooled, height, width,
+                         guidance_scale=5.0):
+        """prompt_embeds: [S, 77+T, 2048] (IP tokens already concatenated, ip_adapter.py:321-322)."""
+        self.do_cfg = guidance_scale > 1.0                                   # custom_pipelines.py:223
+        self.guidance = float(guidance_scale)
+        S = prompt_embeds.shape[0]
+        ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32).repeat(S, 1)   # :277-293
+        if self.do_cfg:                                                      # :295-298 -- order [uncond | cond]
+            ehs = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
+            text = torch.cat([negative_pooled, pooled], 0)
+            ids = torch.cat([ids, ids], 0)
+        else:
+            ehs, text = prompt_embeds, pooled
+        ctx = Ctx(self.device, self.dtype)      # fresh context: the K/V caches must outlive pooled buffers
+        st = self.unet.prepare_conditioning(ctx, ehs, text, ids)
+        self._cond_ctx = ctx
+        self.S, self.H, self.W = S, height // 8, width // 8
+        self.T_total = ehs.shape[1]
+        old = self.st
+        self.st = st
+        if old is not None:                      # keep per-run tables
+            for k in ("latents", "t_table", "step", "in_scale_tab", "ip_scale_tab", "coef_tab"):
+                setattr(st, k, getattr(old, k, None))
+        self.plan = None                         # conditioning buffers changed -> re-record
+        return st
+
+    # -- schedule tables --
+    def set_schedule(self, scheduler, num_inference_steps, control_guidance_start=0.0, control_guidance_end=1.0):
+        scheduler.set_timesteps(num_inference_steps)
+        tab = scheduler.tables()
+        st, dev = self.st, self.device
+        n = num_inference_steps
+        st.t_table = tab["timesteps"].to(dev)
+        st.coef_tab = tab["coef"].contiguous().to(dev)
+        new_in = tab["in_scale"].to(dev) if tab["in_scale"] is not None else None
+        if (new_in is None) != (st.in_scale_tab is None):
+            self.plan = None
+        st.in_scale_tab = new_in
+        from .attention_processor import IPAttnProcessor2_0
+        base = next((p.scale for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor2_0)), 1.0)
+        gate = [0.0 if (i / n < control_guidance_start) or ((i + 1) / n > control_guidance_end) else float(base)
+                for i in range(n)]                                           # custom_pipelines.py:319-329
+        st.ip_scale_tab = torch.tensor(gate, dtype=torch.float32, device=dev)
+        if st.step is None:
+            st.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps = n
+        self.init_noise_sigma = float(tab["init_noise_sigma"])
+        self.plan = None                         # table pointers changed
+
+    def _record(self):
+        st = self.st
+        if st.latents is None or tuple(st.latents.shape) != (self.S, 4, self.H, self.W):
+            st.latents = torch.zeros(self.S, 4, self.H, self.W, dtype=torch.float32, device=self.device)
+        rec = Ctx(self.device, self.dtype, record=True)
+        out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
+        rec.tag = 70
+        rec.ew(L.EW_CFG_STEP, st.latents, a=out, tab=st.coef_tab, step=st.step,
+               i=(self.S, self.H * self.W, 0, int(self.do_cfg), 0, 0), f=(0.0, 0.0, self.guidance, 0.0), descr="cfg+step")
+        rec.ew(L.EW_STEP_SET, st.step, i=(0, 0, 0, 0, 0, 0), descr="step++")
+        if self.use_graph:
+            rec.capture()
+        self.plan = rec
+        self.noise_pred = out
+
+    @torch.no_grad()
+    def denoise(self, latents):
+        """latents: [S, 4, H/8, W/8] unit-variance noise (CPU or device).  Returns final fp32 latents
+        (output_type='latent' of custom_pipelines.py:365-379)."""
+        if self.plan is None:
+            self._record()
+        st = self.st
+        st.latents.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)     # prepare_latents :255-265
+        self.eager.ew(L.EW_STEP_SET, st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
+        for _ in range(self.steps):                                         # :325 -- no host work per step
+            self.plan.replay()
+        return st.latents

@@ -42,3 +42,184 @@ def set_scale(unet, scale):
     for p in unet.attn_processors.values():
         if isinstance(p, IPAttnProcessor2_0):
             p.scale = scale
+
+
+# --------------------------------------------------------------------------------------------
+# Adapter classes (API surface of ip_adapter/ip_adapter.py:69-478 for the SDXL variants)
+# --------------------------------------------------------------------------------------------
+import os
+from typing import List
+
+from .modules import HarmonyAttention, ImageProjModel, Resampler  # noqa: E402,F401
+from .utils import get_generator  # noqa: E402
+
+IPAttnProcessor = IPAttnProcessor2_0
+
+
+class IPAdapter:
+    """``IPAdapter.__init__`` / ``set_ip_adapter`` / ``load_ip_adapter`` / ``get_image_embeds`` / ``set_scale``
+    (ip_adapter.py:70-182).  Differences, all behaviour-compatible: the compute dtype is a parameter (the
+    reference hard-codes fp16 in 8 places), ``number_class_crossattention`` may be None (ip_adapter.py:85
+    crashes), the ``.safetensors`` branch works (ip_adapter.py:137-147 writes a missing key), and an already
+    constructed CLIP vision model / pre-computed CLIP embeddings may be supplied (no network here)."""
+
+    def __init__(self, sd_pipe, image_encoder_path, ip_ckpt, device, num_tokens=4, target_blocks=None,
+                 number_class_crossattention=None, image_encoder=None, dtype=torch.float16, clip_embeddings_dim=1280,
+                 clip_hidden_size=1280):
+        self.device = device
+        self.dtype = dtype
+        self.image_encoder_path = image_encoder_path
+        self.ip_ckpt = ip_ckpt
+        self.num_tokens = num_tokens
+        self.pipe = sd_pipe.to(self.device)
+        self.set_ip_adapter()
+        self.image_encoder = image_encoder
+        self.clip_image_processor = None
+        if image_encoder is None and image_encoder_path is not None:
+            from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection       # ip_adapter.py:81-84
+            self.image_encoder = CLIPVisionModelWithProjection.from_pretrained(image_encoder_path).to(self.device, dtype=dtype)
+            self.clip_image_processor = CLIPImageProcessor()
+        self.clip_embeddings_dim = getattr(getattr(self.image_encoder, "config", None), "projection_dim", clip_embeddings_dim)
+        self.clip_hidden_size = getattr(getattr(self.image_encoder, "config", None), "hidden_size", clip_hidden_size)
+        self.number_class_crossattention = (number_class_crossattention.to(self.device, dtype=dtype)
+                                            if number_class_crossattention is not None else None)
+        self.image_proj_model = self.init_proj()
+        if ip_ckpt is not None:
+            self.load_ip_adapter()
+
+    def init_proj(self):                                                  # ip_adapter.py:91-97
+        return ImageProjModel(cross_attention_dim=self.pipe.unet.config.cross_attention_dim,
+                              clip_embeddings_dim=self.clip_embeddings_dim,
+                              clip_extra_context_tokens=self.num_tokens).to(self.device, dtype=self.dtype)
+
+    def set_ip_adapter(self):                                             # ip_adapter.py:99-125
+        install_ip_processors(self.pipe.unet, num_tokens=self.num_tokens, device=self.device, dtype=self.dtype)
+
+    def load_ip_adapter(self, state_dict=None):                           # ip_adapter.py:135-154
+        if state_dict is None:
+            if os.path.splitext(self.ip_ckpt)[-1] == ".safetensors":
+                from safetensors import safe_open
+                state_dict = {"image_proj": {}, "ip_adapter": {}, "composed_adapter": {}}
+                with safe_open(self.ip_ckpt, framework="pt", device="cpu") as f:
+                    for key in f.keys():
+                        for grp in state_dict:
+                            if key.startswith(grp + "."):
+                                state_dict[grp][key[len(grp) + 1:]] = f.get_tensor(key)
+            else:
+                state_dict = torch.load(self.ip_ckpt, map_location="cpu")
+        self.image_proj_model.load_state_dict(state_dict["image_proj"])
+        if self.number_class_crossattention is not None:
+            self.number_class_crossattention.load_state_dict(state_dict["composed_adapter"])
+        ip_layers = torch.nn.ModuleList(self.pipe.unet.attn_processors.values())     # keys '<idx>.to_k_ip.weight'
+        ip_layers.load_state_dict(state_dict["ip_adapter"])
+
+    def _clip_embeds(self, pil_image, clip_image_embeds):
+        if pil_image is not None:
+            if self.image_encoder is None or self.clip_image_processor is None:
+                raise NotImplementedError("the CLIP image encoder is the step before the hot path (SURVEY.md 8f-4): "
+                                          "pass clip_image_embeds or construct with image_encoder_path")
+            imgs = pil_image if isinstance(pil_image, (list, tuple)) else [pil_image]
+            px = self.clip_image_processor(images=imgs, return_tensors="pt").pixel_values
+            return self.image_encoder(px.to(self.device, dtype=self.dtype)).image_embeds
+        return clip_image_embeds.to(self.device, dtype=self.dtype)
+
+    @torch.inference_mode()
+    def get_image_embeds(self, pil_image=None, clip_image_embeds=None, extra_prompt_embeds=None):   # ip_adapter.py:158-177
+        clip_image_embeds = self._clip_embeds(pil_image, clip_image_embeds)
+        if extra_prompt_embeds is not None and self.number_class_crossattention is not None:
+            extra = extra_prompt_embeds.to(self.device, self.dtype)
+            clip_image_embeds = clip_image_embeds + self.number_class_crossattention(extra, clip_image_embeds)   # :170-173
+        image_prompt_embeds = self.image_proj_model(clip_image_embeds)
+        uncond_image_prompt_embeds = self.image_proj_model(torch.zeros_like(clip_image_embeds))
+        return image_prompt_embeds, uncond_image_prompt_embeds
+
+    def set_scale(self, scale):                                           # ip_adapter.py:179-182
+        set_scale(self.pipe.unet, scale)
+
+    # shared tail of the generate() variants
+    def _run(self, image_prompt_embeds, uncond_image_prompt_embeds, prompt, negative_prompt, num_samples, seed,
+             num_inference_steps, embeds, kwargs):
+        bs, seq_len, _ = image_prompt_embeds.shape
+        tile = lambda t: t.repeat(1, num_samples, 1).view(bs * num_samples, seq_len, -1)        # ip_adapter.py:302-306
+        image_prompt_embeds, uncond_image_prompt_embeds = tile(image_prompt_embeds), tile(uncond_image_prompt_embeds)
+        if embeds is None:
+            embeds = self.pipe.encode_prompt(prompt, num_images_per_prompt=num_samples, do_classifier_free_guidance=True,
+                                             negative_prompt=negative_prompt)
+        pe, ne, ppe, npe = embeds
+        dev = image_prompt_embeds.device
+        pe = torch.cat([pe.to(dev, self.dtype), image_prompt_embeds], dim=1)                    # :321-322
+        ne = torch.cat([ne.to(dev, self.dtype), uncond_image_prompt_embeds], dim=1)
+        self.generator = get_generator(seed, kwargs.pop("generator_device", "cpu"))
+        return self.pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=ppe,
+                         negative_pooled_prompt_embeds=npe, num_inference_steps=num_inference_steps,
+                         generator=self.generator, **kwargs).images
+
+
+class IPAdapterXL(IPAdapter):
+    """ip_adapter.py:249-340."""
+
+    def __init__(self, sd_pipe, image_encoder_path, ip_ckpt, device, num_tokens=4, target_blocks=None, inference=False,
+                 number_class_crossattention=None, **kw):
+        self.inference = inference
+        super().__init__(sd_pipe, image_encoder_path, ip_ckpt, device, num_tokens=num_tokens, target_blocks=target_blocks,
+                         number_class_crossattention=number_class_crossattention, **kw)
+
+    def generate(self, pil_image=None, prompt=None, negative_prompt=None, extra_text=None, scale=1.0, num_samples=4,
+                 seed=None, num_inference_steps=30, clip_image_embeds=None, prompt_embeds=None, extra_prompt_embeds=None,
+                 **kwargs):
+        """Same arguments as the reference; additionally ``clip_image_embeds`` / ``prompt_embeds`` (a 4-tuple as
+        returned by encode_prompt) / ``extra_prompt_embeds`` may be given when no encoders are attached."""
+        self.set_scale(scale)
+        kwargs.pop("number_class_crossattention", None)        # stray kwarg of test.py:38 (swallowed upstream)
+        n = 1 if not isinstance(pil_image, (list, tuple)) else len(pil_image)
+        prompt = prompt if prompt is not None else "best quality, high quality"
+        negative_prompt = negative_prompt if negative_prompt is not None else \
+            "monochrome, lowres, bad anatomy, worst quality, low quality"
+        if not isinstance(prompt, List):
+            prompt = [prompt] * n
+        if not isinstance(negative_prompt, List):
+            negative_prompt = [negative_prompt] * n
+        if extra_prompt_embeds is None and extra_text is not None:      # ip_adapter.py:285-297 (NameError upstream if None)
+            extra_prompt_embeds = self.pipe.encode_prompt(extra_text, num_images_per_prompt=num_samples,
+                                                          do_classifier_free_guidance=True,
+                                                          negative_prompt=negative_prompt)[0]
+        ipe, uipe = self.get_image_embeds(pil_image=pil_image, clip_image_embeds=clip_image_embeds,
+                                          extra_prompt_embeds=extra_prompt_embeds)
+        return self._run(ipe, uipe, prompt, negative_prompt, num_samples, seed, num_inference_steps, prompt_embeds, kwargs)
+
+
+class IPAdapterPlusXL(IPAdapter):
+    """ip_adapter.py:389-478: Resampler over the penultimate CLIP hidden states."""
+
+    def init_proj(self):                                                  # ip_adapter.py:391-403
+        return Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=self.num_tokens,
+                         embedding_dim=self.clip_hidden_size, output_dim=self.pipe.unet.config.cross_attention_dim,
+                         ff_mult=4).to(self.device, dtype=self.dtype)
+
+    @torch.inference_mode()
+    def get_image_embeds(self, pil_image=None, clip_hidden_states=None, uncond_clip_hidden_states=None):   # :405-417
+        if pil_image is not None:
+            if self.image_encoder is None or self.clip_image_processor is None:
+                raise NotImplementedError("CLIP image encoder not attached: pass clip_hidden_states")
+            imgs = pil_image if isinstance(pil_image, (list, tuple)) else [pil_image]
+            px = self.clip_image_processor(images=imgs, return_tensors="pt").pixel_values.to(self.device, dtype=self.dtype)
+            clip_hidden_states = self.image_encoder(px, output_hidden_states=True).hidden_states[-2]
+            uncond_clip_hidden_states = self.image_encoder(torch.zeros_like(px), output_hidden_states=True).hidden_states[-2]
+        c = clip_hidden_states.to(self.device, self.dtype)
+        u = uncond_clip_hidden_states.to(self.device, self.dtype)
+        return self.image_proj_model(c), self.image_proj_model(u)
+
+    def generate(self, pil_image=None, prompt=None, negative_prompt=None, scale=1.0, num_samples=4, seed=None,
+                 num_inference_steps=30, clip_hidden_states=None, uncond_clip_hidden_states=None, prompt_embeds=None,
+                 **kwargs):
+        self.set_scale(scale)
+        n = 1 if not isinstance(pil_image, (list, tuple)) else len(pil_image)
+        prompt = prompt if prompt is not None else "best quality, high quality"
+        negative_prompt = negative_prompt if negative_prompt is not None else \
+            "monochrome, lowres, bad anatomy, worst quality, low quality"
+        if not isinstance(prompt, List):
+            prompt = [prompt] * n
+        if not isinstance(negative_prompt, List):
+            negative_prompt = [negative_prompt] * n
+        ipe, uipe = self.get_image_embeds(pil_image, clip_hidden_states, uncond_clip_hidden_states)
+        return self._run(ipe, uipe, prompt, negative_prompt, num_samples, seed, num_inference_steps, prompt_embeds, kwargs)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libimh_hip.so")
 
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32 = 1, 2, 4, 8, 16
-OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW = 0, 1, 2, 3, 4
+OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL = 0, 1, 2, 3, 4, 5
 EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET = range(8)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
@@ -34,6 +34,12 @@ class AttnArgs(C.Structure):
                 ("Lk2_pad", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldvt", _i32), ("ldk2", _i32), ("ldvt2", _i32), ("ldo", _i32),
                 ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32)]
+
+
+class SmallAttnArgs(C.Structure):
+    _fields_ = [("Q", _vp), ("K", _vp), ("V", _vp), ("O", _vp),
+                ("B", _i32), ("H", _i32), ("Lq", _i32), ("Lk", _i32), ("dq", _i32), ("dv", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32), ("scale", _f32), ("dtype", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -58,6 +64,7 @@ SYMBOLS = [
                                        C.POINTER(C.c_int)]),
     ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("imh_attention", C.c_int, [C.POINTER(AttnArgs), _vp]),
+    ("imh_attention_small", C.c_int, [C.POINTER(SmallAttnArgs), _vp]),
     ("imh_groupnorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_groupnorm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("imh_layernorm", C.c_int, [C.POINTER(NormArgs), _vp]),

@@ -124,6 +124,22 @@ typedef struct imh_attn_args {
 
 int imh_attention(const imh_attn_args* a, void* stream);
 
+/* small generic attention (arbitrary head dims, short sequences), row-major Q/K/V, one softmax:
+ * HarmonyAttention's Cross_Attention (ip_adapter/attention_processor.py:35-56, head_dim 40 / value_dim 64)
+ * and the Resampler's PerceiverAttention core (ip_adapter/resampler.py:66-76).  Once per image. */
+typedef struct imh_small_attn_args {
+    const void* Q;
+    const void* K;
+    const void* V;
+    void* O;
+    int32_t B, H, Lq, Lk, dq, dv;
+    int32_t ldq, ldk, ldv, ldo;
+    float scale;
+    int32_t dtype;
+} imh_small_attn_args;
+
+int imh_attention_small(const imh_small_attn_args* a, void* stream);
+
 /* ---- normalisation ----------------------------------------------------------------------
  * imh_groupnorm: GroupNorm(groups) over NHWC x[B, HW, C] with optional fused SiLU
  *   (diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out).
@@ -177,7 +193,8 @@ int imh_elementwise(int op, const imh_ew_args* a, void* stream);
 
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
-enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4 };
+enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4,
+                   IMH_OP_ATTN_SMALL = 5 };
 
 typedef struct imh_plan imh_plan;
 

@@ -28,7 +28,8 @@ def test_ctypes_structs_match_header_field_order():
     from imagharmony_amd import lib
     hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
     for cname, struct in (("imh_gemm_args", lib.GemmArgs), ("imh_attn_args", lib.AttnArgs),
-                          ("imh_norm_args", lib.NormArgs), ("imh_ew_args", lib.EwArgs)):
+                          ("imh_norm_args", lib.NormArgs), ("imh_ew_args", lib.EwArgs),
+                          ("imh_small_attn_args", lib.SmallAttnArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
