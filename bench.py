@@ -73,7 +73,8 @@ def cpu_baseline(res, ip_tokens, denoise_steps):
     """One fp32 UNet forward of the CPU oracle at res^2, CFG batch 2 (a bounded sample of the workload)."""
     from oracle.pipeline import install_ip_processors
     from oracle.sdxl_unet import UNet2DConditionModel, sdxl_config
-    nthreads = os.cpu_count() or 1
+    # 32 threads: measured best on the 2x64-core EPYC host of the MI355X box (128 / 256 threads are 4-5x slower)
+    nthreads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(nthreads)
     t0 = time.time()
     with torch.device("meta"):

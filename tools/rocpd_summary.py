@@ -1,0 +1,27 @@
+"""Turn a rocprofv3 rocpd results.db (kernel trace) into the per-kernel summary committed under profiles/.
+Usage: python tools/rocpd_summary.py <results.db> <out.md> [title]"""
+import sqlite3
+import sys
+
+
+def main():
+    db, out = sys.argv[1], sys.argv[2]
+    title = sys.argv[3] if len(sys.argv) > 3 else db
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                     "from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    span = c.execute("select min(start), max(end) from kernels").fetchone()
+    with open(out, "w") as f:
+        f.write(f"# {title}\n\nsource: rocprofv3 --kernel-trace --stats (rocpd database), all kernel dispatches of the run\n\n")
+        f.write(f"total kernel time {tot / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches; "
+                f"first-to-last dispatch span {(span[1] - span[0]) / 1e6:.2f} ms\n\n")
+        f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for name, n, s, a, mn, mx in rows:
+            short = name if len(name) < 110 else name[:107] + "..."
+            f.write(f"| `{short}` | {n} | {s / 1e6:.3f} | {a / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * s / tot:.2f} |\n")
+    print(open(out).read()[:3000])
+
+
+if __name__ == "__main__":
+    main()
