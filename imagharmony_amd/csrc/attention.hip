@@ -20,16 +20,24 @@
 
 namespace imh {
 
+int g_attn_force_nw = 0;   // debugging / tuning override (imh_debug_set)
+int g_attn_ablate = 0;     // ablation bits (imh_debug_set key 1): 1 no QK^T, 2 no softmax, 4 no PV, 8 no loads in loop
+
 constexpr int ATT_KV = 64;              // keys per LDS tile
 constexpr int ATT_TILE_BYTES = 64 * 128;
+constexpr int ATT_STAGES = 2;             // K/V^T ring depth (2 measured best in situ: 3.33 ms/forward vs 3.42 at 4 and 3.92 at 3)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+// NW waves per workgroup (32 queries each).  The grid is (ceil(Lq / (32 NW)), H, B): NW is picked by the
+// launcher so that the number of workgroups is a multiple of what the chip holds at once (SDXL: L=4096 ->
+// NW=2, L=1024 -> NW=1, both 1280 workgroups = 5 per CU), instead of 1.25 "rounds" of 4-wave workgroups.
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : (NW == 2 ? 3 : 2))) void attn_kernel(const AttnParams p) {
+    constexpr int RND = 8 / NW;              // staging rounds: NW*8 rows per round, 64 rows per tile
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -37,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const int l32 = lane & 31;
     const int hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 128 + wave * 32 + l32;
+    const int q = blockIdx.x * (32 * NW) + wave * 32 + l32;
     const int qc = min(q, p.Lq - 1);
 
     // Q^T B-operand: lane (col q, half hi) holds d = sd*16 + hi*8 + 0..7
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qp + sd * 16);
     }
 
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E;      // > 0
 
 
     f32x16 fin[2];
@@ -73,13 +81,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             unsigned char* vs = ks + ATT_TILE_BYTES;
             const int kbase = tile * ATT_KV;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = stage_row(i, wave, lane);
+            for (int i = 0; i < RND; ++i) {
+                const int row = i * (NW * 8) + wave * 8 + (lane >> 3);
                 const int ch = stage_chunk_x(row, lane);
                 const T* ksrc = Kp + ((size_t)b * Lkp + kbase + row) * ldk + h * 64 + ch * 8;
-                glds16(ksrc, ks + stage_lds_off(i, wave));
+                glds16(ksrc, ks + (i * (NW * 8) + wave * 8) * 128);
                 const T* vsrc = Vp + ((size_t)h * 64 + row) * ldvt + (size_t)b * Lkp + kbase + ch * 8;
-                glds16(vsrc, vs + stage_lds_off(i, wave));
+                glds16(vsrc, vs + (i * (NW * 8) + wave * 8) * 128);
             }
         };
 
@@ -90,16 +98,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         float m_run = NEG_BIG, l_run = 0.f;
 
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // ring of ATT_STAGES tiles with counted vmcnt: the LDS-DMA queue is never drained inside the loop
+        constexpr int LPT = 2 * RND;           // LDS-DMA instructions per thread per tile
+#pragma unroll
+        for (int s = 0; s < ATT_STAGES - 1; ++s)
+            if (s < ntiles) stage(s, s);
         int cur = 0;
         for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+            if (t + ATT_STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ATT_STAGES - 2) * LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // tile t landed for every wave; tile t-1 fully consumed
+            asm volatile("" ::: "memory");
+            if (t + ATT_STAGES - 1 < ntiles) {
+                int ns = cur + ATT_STAGES - 1;
+                if (ns >= ATT_STAGES) ns -= ATT_STAGES;
+                stage(ns, t + ATT_STAGES - 1);
+            }
             const unsigned char* ks = smem + cur * 2 * ATT_TILE_BYTES;
             const unsigned char* vs = ks + ATT_TILE_BYTES;
             const int kbase = t * ATT_KV;
             const bool second = kbase + 32 < Lk;   // wave-uniform: is the 2nd 32-key sub-tile live?
+            const bool ragged = kbase + ATT_KV > Lk;   // only the last tile of a ragged key set needs masking
 
             // ---- S^T = K Q^T ----
             f32x16 st[2];
@@ -114,37 +133,41 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                     st[kt] = mfma32(kf, qf[sd], st[kt]);
                 }
             }
-            // ---- scale, mask, online softmax (lane-local row; one cross-half exchange) ----
-            float mx = NEG_BIG;
+            // ---- online softmax on RAW scores (scale folded into the exponent: p = exp2(s*c - m*c), c > 0);
+            //      the row is lane-local, one cross-half exchange per tile ----
+            if (ragged) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + kt * 32 + st_key(r, hi);
-                    float s = st[kt][r] * c;
-                    s = key < Lk ? s : NEG_BIG;
-                    st[kt][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
+            }
+            float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
+            const float mc = m_new * c;
             float psum = 0.f;
             v8 pf[2][2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c, -mc));
                     psum += pv;
                     pf[kt][r >> 3][r & 7] = from_f32<T>(pv);
                 }
-            l_run = l_run * alpha + psum;
+            if (__any(m_new != m_run)) {           // wave-uniform: rescale only when some row's max moved
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                m_run = m_new;
+            }
+            l_run += psum;
             // ---- O^T += V^T P^T ----
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
@@ -157,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                         o[dt] = mfma32(vf, pf[kt][s], o[dt]);
                     }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
+            asm volatile("" ::: "memory");
+            if (++cur == ATT_STAGES) cur = 0;
         }
+        __builtin_amdgcn_s_barrier();          // the next pass refills the ring from slot 0
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = wgt / l_tot;
 #pragma unroll
@@ -257,10 +280,16 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
         return IMH_ERR_SHAPE;
     }
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("attention: empty problem"); return IMH_ERR_SHAPE; }
-    dim3 grid((p.Lq + 127) / 128, p.H, p.B);
-    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, stream, p);
-    else if (dtype == IMH_DT_F16) hipLaunchKernelGGL((attn_kernel<f16_t>), grid, dim3(256), 0, stream, p);
-    else { set_error("attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    // 4 waves share every K / V^T tile; finer workgroups (NW = 1 | 2, kept for experiments through
+    // imh_debug_set) balance the grid better but re-read K/V and measured 25-50 % slower on MI355X.
+    int nw = g_attn_force_nw;
+    if (nw != 1 && nw != 2 && nw != 4) nw = 4;
+    dim3 grid((p.Lq + 32 * nw - 1) / (32 * nw), p.H, p.B);
+#define IMH_ATT_LAUNCH(TT, NWV) hipLaunchKernelGGL((attn_kernel<TT, NWV>), grid, dim3(64 * NWV), 0, stream, p)
+    if (dtype == IMH_DT_BF16) { if (nw == 4) IMH_ATT_LAUNCH(bf16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(bf16_t, 2); else IMH_ATT_LAUNCH(bf16_t, 1); }
+    else { if (nw == 4) IMH_ATT_LAUNCH(f16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(f16_t, 2); else IMH_ATT_LAUNCH(f16_t, 1); }
+#undef IMH_ATT_LAUNCH
     return check_launch("attn_kernel");
 }
 

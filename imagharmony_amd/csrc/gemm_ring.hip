@@ -1,0 +1,444 @@
+// Multi-stage ("ring") variant of the MFMA GEMM / implicit-GEMM conv kernel for gfx950.
+//
+// Same operand layout, swizzles, fragment maps and epilogue as gemm.hip, but:
+//   * S LDS stages with COUNTED vmcnt: S-1 tiles are in flight while one is consumed, the LDS-DMA
+//     queue is never drained inside the K loop (cdna_hip_programming.md T3/T4: "never vmcnt(0) in the
+//     main loop"), one raw s_barrier per K-tile;
+//   * WM x WN waves (up to 8) and tiles up to 256x256, i.e. fewer L2->LDS bytes per FLOP.
+// gemm.hip's two-stage kernel is load-latency bound (one 32 KB tile in flight per workgroup,
+// profiles/r01_*); this kernel exists to lift that.
+#include "imh_common.h"
+#include "imh_kernels.h"
+#include "imh_gemm_epilogue.h"
+#include <type_traits>
+
+namespace imh {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S, bool CONV>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_ring_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int NT = 64 * NW;
+    constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int RPR = NW * 8;                    // tile rows staged per round by the whole block
+    constexpr int RX = BM / RPR, RW = BN / RPR;
+    constexpr int LP = RX + RW;                    // LDS-DMA instructions per thread per K-tile
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int WT_BYTES = BN * GEMM_ROW_BYTES;
+    constexpr int STAGE = XT_BYTES + WT_BYTES;
+    static_assert(FN == 4 || FN == 2, "lane owns 16 or 8 output columns");
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "staging rounds");
+    static_assert((S - 2) * LP <= 63, "vmcnt range");
+    typedef typename Vec<T>::v8 v8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    const int nkt = p.K / GEMM_BK;
+    const int z = blockIdx.y;
+    const int per = (nkt + p.splits - 1) / p.splits;
+    const int kt0 = z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    const int nt = max(0, kt1 - kt0);
+
+    const unsigned char* zero = g_zero_page;
+    const int srow = wave * 8 + (lane >> 3);
+
+    const unsigned char* xbase[RX];
+    int xstep[RX];
+    int cb[RX], coy[RX], cox[RX];
+    bool cvalid[RX];
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int row = i * RPR + srow;
+        const int c = stage_chunk_x(row, lane);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        if (!CONV) {
+            xbase[i] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+            xstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wo;
+            cb[i] = b; coy[i] = oy; cox[i] = rem - oy * p.Wo; cvalid[i] = ok;
+            xbase[i] = zero + c * 16;
+            xstep[i] = 0;
+        }
+    }
+    const unsigned char* wbase[RW];
+    int wstep[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int row = i * RPR + srow;
+        const int c = stage_chunk_w(row, lane, FN);
+        const int n = n0 + row;
+        const bool ok = n < p.N;
+        wbase[i] = ok ? (const unsigned char*)p.W + ((size_t)n * p.ldw) * sizeof(T) + c * 16 : zero + c * 16;
+        wstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+    }
+    const int cpt = CONV ? p.Cin / GEMM_BK : 1;
+
+    auto stage = [&](int slot, int kt) {
+        unsigned char* xs = smem + slot * STAGE;
+        unsigned char* ws = xs + XT_BYTES;
+        if (CONV) {
+            const int tap = kt / cpt;
+            const int ct = kt - tap * cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+#pragma unroll
+            for (int i = 0; i < RX; ++i) {
+                const int c = stage_chunk_x(i * RPR + srow, lane);
+                const int iy = coy[i] * p.stride + ky - 1;
+                const int ix = cox[i] * p.stride + kx - 1;
+                const bool ok = cvalid[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                const size_t pix = ((size_t)cb[i] * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
+                const unsigned char* src = ok
+                    ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
+                    : zero + c * 16;
+                glds16(src, xs + (i * RPR + wave * 8) * GEMM_ROW_BYTES);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RX; ++i)
+                glds16(xbase[i] + (size_t)kt * xstep[i], xs + (i * RPR + wave * 8) * GEMM_ROW_BYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            glds16(wbase[i] + (size_t)kt * wstep[i], ws + (i * RPR + wave * 8) * GEMM_ROW_BYTES);
+    };
+
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int xr = wm * TM + (lane & 15);
+        const int wr = wn * TN + w_frag_row(lane & 15, 0, FN);
+        xoff[kk] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
+        woff[kk] = tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: S-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nt) stage(s, kt0 + s);
+
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        // tile t must have landed; tiles t+1 .. t+S-2 may stay in flight
+        if (t + S - 2 < nt) wait_vmcnt<(S - 2) * LP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // everyone's part of tile t is in LDS; tile t-1 fully consumed
+        asm volatile("" ::: "memory");
+        if (t + S - 1 < nt) {
+            int ns = slot + S - 1;
+            if (ns >= S) ns -= S;
+            stage(ns, kt0 + t + S - 1);           // refill the slot tile t-1 used
+        }
+        const unsigned char* xs = smem + slot * STAGE;
+        const unsigned char* ws = xs + XT_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 xf[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[i] = *(const v8*)(xs + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(ws + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+        }
+        asm volatile("" ::: "memory");
+        if (++slot == S) slot = 0;
+    }
+
+    const int nb = n0 + wn * TN + (lane >> 4) * 4 * FN;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        if (m >= p.M || nb >= p.N) continue;
+        float v[4 * FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+        if (p.splits > 1) {
+            float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+            if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+#pragma unroll
+                for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+            }
+        } else {
+            epilogue_store<T, FN>(p, v, m, nb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "KG2": one 8-wave workgroup per output tile, the K range split between two 4-wave groups that each run
+// the two-stage LDS pipeline of gemm.hip on alternate K-tiles; the two partial accumulators are exchanged
+// through LDS and each group finishes half of the tile.  Same LDS/occupancy footprint per CU as two
+// co-resident workgroups of gemm.hip, but every tile finishes in half the K iterations -- for the many
+// SDXL GEMMs whose tile count is below the CU count (M = 2048, N = 1280) the kernel time is the length of
+// one workgroup's K loop, not the throughput.
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
+    constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr int RX = BM / 32, RW = BN / 32;
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int WT_BYTES = BN * GEMM_ROW_BYTES;
+    constexpr int STAGE = XT_BYTES + WT_BYTES;
+    constexpr int GROUP_BYTES = 2 * STAGE;
+    static_assert(FM % 2 == 0, "the two groups split the token fragments");
+    static_assert((FM / 2) * FN * 4 * 256 * 4 <= GROUP_BYTES, "exchange buffer fits a group's stages");
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2;               // K-group
+    const int wave = wave8 & 3;               // wave inside the group (2x2 over the tile)
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned char* gmem = smem + grp * GROUP_BYTES;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int nkt = p.K / GEMM_BK;
+    const int z = blockIdx.y;
+    const int per = (nkt + p.splits - 1) / p.splits;
+    const int kt0 = z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    const int niter = (max(0, kt1 - kt0) + 1) / 2;    // lockstep iterations; group g takes kt0 + 2*i + g
+
+    const unsigned char* zero = g_zero_page;
+    const unsigned char* xbase[RX];
+    int xstep[RX];
+    int cb[RX], coy[RX], cox[RX];
+    bool cvalid[RX];
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int row = stage_row(i, wave, lane);
+        const int c = stage_chunk_x(row, lane);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        if (!CONV) {
+            xbase[i] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+            xstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wo;
+            cb[i] = b; coy[i] = oy; cox[i] = rem - oy * p.Wo; cvalid[i] = ok;
+            xbase[i] = zero + c * 16;
+            xstep[i] = 0;
+        }
+    }
+    const unsigned char* wbase[RW];
+    int wstep[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int row = stage_row(i, wave, lane);
+        const int c = stage_chunk_w(row, lane, FN);
+        const int n = n0 + row;
+        const bool ok = n < p.N;
+        wbase[i] = ok ? (const unsigned char*)p.W + ((size_t)n * p.ldw) * sizeof(T) + c * 16 : zero + c * 16;
+        wstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+    }
+    const int cpt = CONV ? p.Cin / GEMM_BK : 1;
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xs = gmem + buf * STAGE;
+        unsigned char* ws = xs + XT_BYTES;
+        if (CONV) {
+            const int tap = kt / cpt;
+            const int ct = kt - tap * cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+#pragma unroll
+            for (int i = 0; i < RX; ++i) {
+                const int c = stage_chunk_x(stage_row(i, wave, lane), lane);
+                const int iy = coy[i] * p.stride + ky - 1;
+                const int ix = cox[i] * p.stride + kx - 1;
+                const bool ok = cvalid[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                const size_t pix = ((size_t)cb[i] * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
+                const unsigned char* src = ok
+                    ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
+                    : zero + c * 16;
+                glds16(src, xs + stage_lds_off(i, wave));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RX; ++i) glds16(xbase[i] + (size_t)kt * xstep[i], xs + stage_lds_off(i, wave));
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) glds16(wbase[i] + (size_t)kt * wstep[i], ws + stage_lds_off(i, wave));
+    };
+
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        xoff[kk] = xfrag_off(lane, wm, BM, kk);
+        woff[kk] = wfrag_off(lane, wn, BN, kk);
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (niter > 0) {
+        if (kt0 + grp < kt1) stage(0, kt0 + grp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int it = 0; it < niter; ++it) {
+            const int kt = kt0 + 2 * it + grp;
+            if (kt + 2 < kt1) stage(cur ^ 1, kt + 2);
+            if (kt < kt1) {
+                const unsigned char* xs = gmem + cur * STAGE;
+                const unsigned char* ws = xs + XT_BYTES;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    v8 xf[FM], wf[FN];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) xf[i] = *(const v8*)(xs + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(ws + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- exchange: group g keeps token fragments [g*FM/2, (g+1)*FM/2) and receives the partner's partials.
+    //      Every accumulator index below is a compile-time constant (a runtime index would push acc[] to
+    //      scratch): the group id is lifted to a template constant. ----
+    const int nb = n0 + out_col(lane, wn, BN);
+    auto finish = [&](auto G) {
+        constexpr int g = decltype(G)::value;
+        float* mine = (float*)(smem + g * GROUP_BYTES);                 // written by me, read by the partner
+        const float* theirs = (const float*)(smem + (g ^ 1) * GROUP_BYTES);
+        const int t256 = tid & 255;
+#pragma unroll
+        for (int ii = 0; ii < FM / 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mine[((ii * FN + j) * 4 + r) * 256 + t256] = acc[(g ^ 1) * (FM / 2) + ii][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < FM / 2; ++ii) {
+            constexpr int dummy = 0; (void)dummy;
+            const int m = m0 + out_row(lane, wm, BM, g * (FM / 2) + ii);
+            float v[4 * FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[j * 4 + r] = acc[g * (FM / 2) + ii][j][r] + theirs[((ii * FN + j) * 4 + r) * 256 + t256];
+            if (m >= p.M || nb >= p.N) continue;
+            if (p.splits > 1) {
+                float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+                if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+#pragma unroll
+                    for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+                }
+            } else {
+                epilogue_store<T, FN>(p, v, m, nb);
+            }
+        }
+    };
+    if (grp == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+}
+
+template <typename T, int BM, int BN, bool CONV>
+static int launch_kg2(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t smem = 2 * 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
+    auto kern = gemm_kg2_kernel<T, BM, BN, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(512), smem, stream, p);
+    return check_launch("gemm_kg2_kernel");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S, bool CONV>
+static int launch_ring(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
+    auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, S, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * WM * WN), smem, stream, p);
+    return check_launch("gemm_ring_kernel");
+}
+
+// variant codes (bm field of the config): 256 -> 256x{128,256}; 1128 -> 128x128 4-stage, 1 block/CU
+template <typename T, bool CONV>
+static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
+    if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
+    if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
+    if (bm == 1128 && bn == 128) return launch_ring<T, 128, 128, 2, 2, 4, CONV>(p, stream);
+    if (bm == 2128 && bn == 128) return launch_ring<T, 128, 128, 2, 2, 3, CONV>(p, stream);
+    if (bm == 1256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 2, CONV>(p, stream);
+    if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);
+    if (bm == 3128 && bn == 64) return launch_kg2<T, 128, 64, CONV>(p, stream);
+    if (bm == 3064 && bn == 128) return launch_kg2<T, 64, 128, CONV>(p, stream);
+    if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
+    set_error("gemm_ring: unsupported variant %dx%d", bm, bn);
+    return IMH_ERR_ARG;
+}
+
+int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream) {
+    if (dtype == IMH_DT_BF16) return conv ? ring_typed<bf16_t, true>(p, bm, bn, stream) : ring_typed<bf16_t, false>(p, bm, bn, stream);
+    if (dtype == IMH_DT_F16) return conv ? ring_typed<f16_t, true>(p, bm, bn, stream) : ring_typed<f16_t, false>(p, bm, bn, stream);
+    set_error("gemm_ring: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
+}
+
+}  // namespace imh

@@ -1,0 +1,138 @@
+// Shared GEMM epilogue (bias / time-embedding row-add / activation / GEGLU / residual / V^T permutation),
+// used by gemm.hip and gemm_ring.hip.
+#pragma once
+#include "imh_common.h"
+#include "imh_kernels.h"
+
+namespace imh {
+
+enum : int {
+    GF_GEGLU = 1,      // columns interleaved (value, gate): out[n/2] = a * gelu(g)
+    GF_ACT_GELU = 2,   // exact-erf GELU on the (biased) result
+    GF_ACT_SILU = 4,
+    GF_VT_PERM = 8,    // permute each 16-column group [0-3,8-11,4-7,12-15] (attention V^T layout)
+    GF_OUT_F32 = 16,   // store fp32 instead of T
+};
+
+// vector load of CNT (4 | 8 | 16) consecutive T values into floats (16-B / 8-B accesses)
+template <typename T, int CNT>
+__device__ __forceinline__ void ldv(const T* p, float* o) {
+    if constexpr (CNT == 4) {
+        typename Vec<T>::v4 t = *(const typename Vec<T>::v4*)p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = to_f32(t[e]);
+    } else {
+#pragma unroll
+        for (int q0 = 0; q0 < CNT; q0 += 8) {
+            typename Vec<T>::v8 t = *(const typename Vec<T>::v8*)(p + q0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[q0 + e] = to_f32(t[e]);
+        }
+    }
+}
+template <typename T, int CNT>
+__device__ __forceinline__ void stv(T* p, const float* v) {
+    if constexpr (CNT == 4) {
+        typename Vec<T>::v4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = from_f32<T>(v[e]);
+        *(typename Vec<T>::v4*)p = t;
+    } else {
+#pragma unroll
+        for (int q0 = 0; q0 < CNT; q0 += 8) {
+            typename Vec<T>::v8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = from_f32<T>(v[q0 + e]);
+            *(typename Vec<T>::v8*)(p + q0) = t;
+        }
+    }
+}
+
+// Epilogue of one lane: NV = 4*FN consecutive columns nb.. of row m.
+// Fast path (whole vector in range, 16-B aligned operands): vector loads/stores only.
+template <typename T, int FN>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4 * FN], int m, int nb) {
+    constexpr int NV = 4 * FN;
+    constexpr int NH = NV / 2;
+    if ((p.flags & GF_VT_PERM) && FN == 4) {   // V^T key permutation: swap the 2nd and 3rd run of 4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float t = v[4 + r]; v[4 + r] = v[8 + r]; v[8 + r] = t; }
+    }
+    const T* bias = (const T*)p.bias;
+    const T* rowadd = p.rowadd ? (const T*)p.rowadd + (size_t)(m / p.rows_per_batch) * p.ldra : nullptr;
+    const T* res = (const T*)p.residual;
+    const int N = p.N;
+    const bool geglu = p.flags & GF_GEGLU;
+    const bool fast = (nb + NV <= N) && !(p.ldy & 7) && (!res || !(p.ldr & 7)) && (!rowadd || !(p.ldra & 7));
+    float t[NV];
+    if (fast) {
+        if (bias) { ldv<T, NV>(bias + nb, t);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += t[q]; }
+        if (rowadd) { ldv<T, NV>(rowadd + nb, t);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += t[q]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) {
+            if (bias) v[q] += to_f32(bias[nb + q]);
+            if (rowadd) v[q] += to_f32(rowadd[nb + q]);
+        }
+    }
+    if (p.flags & GF_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = gelu_erf_f(v[q]);
+    }
+    if (p.flags & GF_ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = silu_f(v[q]);
+    }
+    if (geglu) {       // (value, gate) pairs -> NH outputs at column nb/2 of an [M, N/2] result
+        const int ob = nb >> 1, NO = N >> 1;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) v[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
+        T* y = (T*)p.Y + (size_t)m * p.ldy + ob;
+        if (fast) {
+            if (res) { ldv<T, NH>(res + (size_t)m * p.ldr + ob, t);
+#pragma unroll
+                for (int q = 0; q < NH; ++q) v[q] += t[q]; }
+            stv<T, NH>(y, v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NH; ++q) if (ob + q < NO) {
+                if (res) v[q] += to_f32(res[(size_t)m * p.ldr + ob + q]);
+                y[q] = from_f32<T>(v[q]);
+            }
+        }
+        return;
+    }
+    if (res) {
+        const T* rr = res + (size_t)m * p.ldr + nb;
+        if (fast) { ldv<T, NV>(rr, t);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += t[q]; }
+        else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] += to_f32(rr[q]);
+        }
+    }
+    if (p.flags & GF_OUT_F32) {
+        float* y = (float*)p.Y + (size_t)m * p.ldy + nb;
+        if (fast && !(p.ldy & 3)) {
+#pragma unroll
+            for (int q0 = 0; q0 < NV; q0 += 4) *(f32x4*)(y + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (nb + q < N) y[q] = v[q];
+        }
+        return;
+    }
+    T* y = (T*)p.Y + (size_t)m * p.ldy + nb;
+    if (fast) stv<T, NV>(y, v);
+    else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (nb + q < N) y[q] = from_f32<T>(v[q]);
+    }
+}
+
+}  // namespace imh

@@ -42,7 +42,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
         const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
-        for (int pix = start + pl; pix < end; pix += P) {
+        int pix = start + pl;
+        for (; pix + 3 * P < end; pix += 4 * P) {
+            v8 v0 = *(const v8*)(x + (size_t)pix * C);
+            v8 v1 = *(const v8*)(x + (size_t)(pix + P) * C);
+            v8 v2 = *(const v8*)(x + (size_t)(pix + 2 * P) * C);
+            v8 v3 = *(const v8*)(x + (size_t)(pix + 3 * P) * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
+                s[e] += (f0 + f1) + (f2 + f3);
+                q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+            }
+        }
+        for (; pix < end; pix += P) {
             v8 v = *(const v8*)(x + (size_t)pix * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { float f = to_f32(v[e]); s[e] += f; q[e] += f * f; }
@@ -69,18 +82,28 @@ template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk) {
     typedef typename Vec<T>::v8 v8;
     __shared__ float mean_s[64], rstd_s[64];
+    __shared__ double part_s[16][64], part_q[16][64];
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
     const int b = blockIdx.y, blk = blockIdx.x;
     const int ppb = (p.HW + nblk - 1) / nblk;
     const int start = blk * ppb, end = min(p.HW, start + ppb);
     const int t = threadIdx.x;
+    {   // 16 slices x groups threads sum the per-block partials, then a fixed-order combine (deterministic)
+        const int g = t % 32, sl = t / 32;           // GN_THREADS = 512 -> 16 slices of 32 lanes
+        for (int gg = g; gg < p.groups; gg += 32) {
+            double s = 0.0, q = 0.0;
+            for (int k = sl; k < nblk; k += 16) {
+                const float* pp = p.partial + (((size_t)b * nblk + k) * p.groups + gg) * 2;
+                s += pp[0]; q += pp[1];
+            }
+            part_s[sl][gg] = s; part_q[sl][gg] = q;
+        }
+    }
+    __syncthreads();
     if (t < p.groups) {
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            const float* pp = p.partial + (((size_t)b * nblk + k) * p.groups + t) * 2;
-            s += pp[0]; q += pp[1];
-        }
+        for (int sl = 0; sl < 16; ++sl) { s += part_s[sl][t]; q += part_q[sl][t]; }
         const double n = (double)p.HW * (C / p.groups);
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -106,8 +129,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
         }
         const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
         T* y = (T*)p.y + ((size_t)b * p.HW) * C + cl * 8;
-        for (int pix = start + pl; pix < end; pix += P) {
-            v8 v = *(const v8*)(x + (size_t)pix * C);
+        auto one = [&](const v8& v, size_t off) {
             v8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -115,8 +137,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
                 if (p.silu) f = silu_f(f);
                 o[e] = from_f32<T>(f);
             }
-            *(v8*)(y + (size_t)pix * C) = o;
+            *(v8*)(y + off) = o;
+        };
+        int pix = start + pl;
+        for (; pix + 3 * P < end; pix += 4 * P) {
+            const size_t o0 = (size_t)pix * C, o1 = (size_t)(pix + P) * C, o2 = (size_t)(pix + 2 * P) * C, o3 = (size_t)(pix + 3 * P) * C;
+            v8 v0 = *(const v8*)(x + o0), v1 = *(const v8*)(x + o1), v2 = *(const v8*)(x + o2), v3 = *(const v8*)(x + o3);
+            one(v0, o0); one(v1, o1); one(v2, o2); one(v3, o3);
         }
+        for (; pix < end; pix += P) one(*(const v8*)(x + (size_t)pix * C), (size_t)pix * C);
     }
 }
 
@@ -139,69 +168,78 @@ int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
     return check_launch("groupnorm");
 }
 
-// ---- LayerNorm: one wave per row, the row lives in registers (C <= 4096) ----
-template <typename T, int NCH>
+// ---- LayerNorm: one wave handles ROWS rows at once (all loads issued before the first reduction), the rows
+//      live in registers (C <= 4096) ----
+template <typename T, int NCH, int ROWS>
 __global__ __launch_bounds__(256) void ln_kernel(const NormParams p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= p.rows) return;
     const int C = p.C, CL = C >> 3;
-    const T* x = (const T*)p.x + (size_t)row * C;
-    float v[NCH][8];
-    float s = 0.f;
+    float v[ROWS][NCH][8];
+    float s[ROWS];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < CL) {
-            v8 t = *(const v8*)(x + ch * 8);
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = min(row0 + r, p.rows - 1);
+        const T* x = (const T*)p.x + (size_t)row * C;
+        s[r] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[k][e] = to_f32(t[e]); s += v[k][e]; }
-        } else {
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < CL) {
+                v8 t = *(const v8*)(x + ch * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+                for (int e = 0; e < 8; ++e) { v[r][k][e] = to_f32(t[e]); s[r] += v[r][k][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[r][k][e] = 0.f;
+            }
         }
     }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < CL) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
     const T* ga = (const T*)p.gamma;
     const T* be = (const T*)p.beta;
-    T* y = (T*)p.y + (size_t)row * C;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < CL) {
-            v8 g8, b8, o;
-            if (ga) g8 = *(const v8*)(ga + ch * 8);
-            if (be) b8 = *(const v8*)(be + ch * 8);
+    for (int r = 0; r < ROWS; ++r) {
+        const float mean = wave_sum(s[r]) / C;
+        float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = (v[k][e] - mean) * rstd;
-                if (ga) f *= to_f32(g8[e]);
-                if (be) f += to_f32(b8[e]);
-                o[e] = from_f32<T>(f);
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < CL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[r][k][e] - mean; q += d * d; }
             }
-            *(v8*)(y + ch * 8) = o;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
+        if (row0 + r >= p.rows) continue;
+        T* y = (T*)p.y + (size_t)(row0 + r) * C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < CL) {
+                v8 g8, b8, o;
+                if (ga) g8 = *(const v8*)(ga + ch * 8);
+                if (be) b8 = *(const v8*)(be + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (v[r][k][e] - mean) * rstd;
+                    if (ga) f *= to_f32(g8[e]);
+                    if (be) f += to_f32(b8[e]);
+                    o[e] = from_f32<T>(f);
+                }
+                *(v8*)(y + ch * 8) = o;
+            }
         }
     }
 }
 
 template <typename T>
 static int ln_typed(const NormParams& p, hipStream_t stream) {
-    dim3 grid((p.rows + 3) / 4);
     const int cl = p.C >> 3;
-    if (cl <= 128) hipLaunchKernelGGL((ln_kernel<T, 2>), grid, dim3(256), 0, stream, p);
-    else if (cl <= 256) hipLaunchKernelGGL((ln_kernel<T, 4>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((ln_kernel<T, 8>), grid, dim3(256), 0, stream, p);
+    if (cl <= 128) hipLaunchKernelGGL((ln_kernel<T, 2, 1>), dim3((p.rows + 3) / 4), dim3(256), 0, stream, p);
+    else if (cl <= 256) hipLaunchKernelGGL((ln_kernel<T, 4, 1>), dim3((p.rows + 3) / 4), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((ln_kernel<T, 8, 1>), dim3((p.rows + 3) / 4), dim3(256), 0, stream, p);
     return check_launch("ln_kernel");
 }
 

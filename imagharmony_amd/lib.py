@@ -59,6 +59,7 @@ class EwArgs(C.Structure):
 SYMBOLS = [
     ("imh_abi_version", C.c_int, []),
     ("imh_last_error", C.c_char_p, []),
+    ("imh_debug_set", C.c_int, [C.c_int, C.c_int]),
     ("imh_gemm", C.c_int, [C.POINTER(GemmArgs), _vp]),
     ("imh_gemm_pick_config", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]),

@@ -219,6 +219,9 @@ int imh_plan_time_ops(imh_plan* p, void* stream, float* ms, int n);
 int imh_plan_get_tag(const imh_plan* p, int index);
 int imh_plan_get_kind(const imh_plan* p, int index);
 
+/* tuning / debugging knobs (key 0: force attention waves-per-workgroup to 1|2|4, 0 = auto) */
+int imh_debug_set(int key, int value);
+
 const char* imh_last_error(void);
 int imh_abi_version(void);
 

@@ -101,38 +101,30 @@ def sweep_shapes(rec, dtype):
             B, H, W, Cin, stride, up = geom
             x = torch.randn(B, H, W, Cin, device=DEV).to(dtype)
             w = (torch.randn(N, K, device=DEV) * K ** -0.5).to(dtype)
-            call = lambda cfg: ctx.conv3x3(x, w, stride=stride, up=up, cfg=cfg, out=out)
+            call = lambda cfg, c=None: (c or ctx).conv3x3(x, w, stride=stride, up=up, cfg=cfg, out=out)
             Ho, Wo = ((H << up) - 1) // stride + 1, ((W << up) - 1) // stride + 1
             out = torch.empty(B, Ho, Wo, N, device=DEV, dtype=dtype)
         else:
             x = torch.randn(M, K, device=DEV).to(dtype)
             w = (torch.randn(N, K, device=DEV) * K ** -0.5).to(dtype)
             out = torch.empty(M, N, device=DEV, dtype=dtype)
-            call = lambda cfg: ctx.gemm(x, w, cfg=cfg, out=out)
+            call = lambda cfg, c=None: (c or ctx).gemm(x, w, cfg=cfg, out=out)
         nkt = K // 64
         res = []
+        cands = []
         for bm in (128, 64):
             for bn in (128, 64):
                 for sp in (1, 2, 4, 8):
-                    if sp > 1 and nkt // sp < 2:
+                    if sp > 1 and (nkt // sp < 4 or -(-M // bm) * -(-N // bn) * sp > 2048):
                         continue
-                    tiles = -(-M // bm) * -(-N // bn)
-                    if sp > 1 and tiles * sp > 4096:
-                        continue
-                    cfg = (bm, bn, sp)
-                    try:
-                        for _ in range(2):
-                            call(cfg)
-                        torch.cuda.synchronize()
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(8):
-                            call(cfg)
-                        e1.record()
-                        torch.cuda.synchronize()
-                        res.append((e0.elapsed_time(e1) / 8, cfg))
-                    except Exception as ex:          # noqa: BLE001
-                        print("  cfg failed", cfg, ex)
+                    cands.append((bm, bn, sp))
+        cands += [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3128, 128, 2), (3064, 64, 1), (3128, 64, 1), (3064, 128, 1)]
+        from tools.gemm_bench import graph_time
+        for cfg in cands:
+            try:
+                res.append((graph_time(lambda c: call(cfg, c), dtype, n=10, reps=2), cfg))
+            except Exception as ex:          # noqa: BLE001
+                print("  cfg failed", cfg, ex)
         res.sort()
         best_ms, best = res[0]
         hb = ctx._config(M, N, K, conv, 0)
