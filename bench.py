@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--ip-tokens", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=1024)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
+                    "single-GPU testing of the multi-rank control path)")
     return ap.parse_args()
 
 
@@ -114,9 +116,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
     if a.gpus != world and rank == 0 and world == 1 and a.gpus > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE=1; launch with torch.distributed.run", file=sys.stderr)
+    if os.environ.get("IMH_BENCH_SHARE_GPU") == "1":      # testing aid: every rank on GPU 0 (needs --backend gloo)
+        local = 0
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]

@@ -89,3 +89,34 @@ def test_ipadapterxl_generate_call_sequence():
     d = ip.generate(seed=43, scale=1.0, **kw)
     assert a.shape == (1, 4, 32, 32) and torch.isfinite(a).all()
     assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+
+
+def test_pns_single_rank_on_device():
+    """PNS driver end-to-end on one GPU: 3 candidate seeds through the HIP engine (2-step preview), winner re-denoised
+    with more steps; the selection must be reproducible and the winner's latent must equal a direct denoise of that seed."""
+    from imagharmony_amd import pns
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    pipe = StableDiffusionXLCustomPipeline(hu, scheduler=hs.DDIMScheduler(), device=DEV, dtype=dtype)
+    cd = ocfg.cross_attention_dim
+    pe, ne = det_randn((1, 81, cd), 4), det_randn((1, 81, cd), 5)
+    po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
+    eng = pipe.engine
+    eng.set_conditioning(pe, ne, po, no, 256, 256, guidance_scale=5.0)
+
+    def preview(noise):
+        eng.set_schedule(pipe.scheduler, 2)
+        return eng.denoise(noise).clone()
+
+    def final(noise):
+        eng.set_schedule(pipe.scheduler, 3)
+        return eng.denoise(noise).clone()
+
+    r1 = pns.run_pns(preview, [3, 9, 27], (1, 4, 32, 32), device=DEV, final_fn=final)
+    r2 = pns.run_pns(preview, [3, 9, 27], (1, 4, 32, 32), device=DEV, final_fn=final)
+    assert r1["best_seed"] == r2["best_seed"] and torch.equal(r1["latents"], r2["latents"])
+    assert torch.equal(r1["scores"], r2["scores"]) and torch.isfinite(r1["scores"]).all()
+    direct = final(pns.seed_latents(r1["best_seed"], (1, 4, 32, 32)))
+    assert torch.equal(direct, r1["latents"])

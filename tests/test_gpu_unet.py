@@ -40,6 +40,7 @@ def build_pair(dtype, num_tokens=4, scale=0.8):
 
 
 def inputs(ocfg, B=2, T=4, hw=32):
+    """BASELINE.json shape families on the reduced-width UNet: T image tokens appended after 77 text tokens"""
     x = det_randn((B, 4, hw, hw), 3)
     ehs = det_randn((B, 77 + T, ocfg.cross_attention_dim), 4)
     te = det_randn((B, ocfg.pooled_dim), 6)
@@ -84,3 +85,17 @@ def test_unet_recorded_plan_equals_eager():
     rec.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.view(2, 32, 32, 4).permute(0, 3, 1, 2), y_eager)
+
+
+@pytest.mark.parametrize("dtype,B,T", [(torch.float16, 4, 16), (torch.bfloat16, 2, 32), (torch.bfloat16, 1, 4)])
+def test_unet_forward_batch_and_ip_token_variants(dtype, B, T):
+    """configs[3]-like (batch 4, Resampler num_queries=16, fp16) and configs[4]-like (two 16-token embeds = 32
+    image tokens) on the reduced-width UNet, plus an odd batch."""
+    ou, hu, ocfg = build_pair(dtype, num_tokens=T)
+    x, ehs, te, ids = inputs(ocfg, B=B, T=T)
+    with torch.no_grad():
+        ref = ou(x, torch.tensor(77.0), ehs, added_cond_kwargs={"text_embeds": te, "time_ids": ids})[0]
+    y = hu(x.to(DEV), torch.tensor(77.0), ehs.to(DEV, dtype),
+           added_cond_kwargs={"text_embeds": te.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
+    r = rel_rms(y.float().cpu(), ref)
+    assert r < TOL[dtype], f"B={B} T={T}: rel-rms {r:.3e}"
