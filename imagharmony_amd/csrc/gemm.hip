@@ -45,10 +45,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     // ---- tile coordinates; blockIdx.x walks N fastest inside an M panel so that concurrently
     //      resident blocks share the token panel in L2 ----
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
 
     // ---- split-K range ----
     const int nkt = p.K / GEMM_BK;
@@ -226,10 +224,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 
 template <typename T, int BM, int BN, bool CONV>
 static int launch_tile(const GemmParams& p, hipStream_t stream) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmParams q = p;
+    int tiles;
+    xcd_partition(q, BM, BN, &tiles);
     const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
     dim3 grid(tiles, p.splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV>), grid, dim3(256), smem, stream, q);
     return check_launch("gemm_kernel");
 }
 

@@ -42,10 +42,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_ring_kernel(const GemmPa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
 
     const int nkt = p.K / GEMM_BK;
     const int z = blockIdx.y;
@@ -226,10 +224,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     unsigned char* gmem = smem + grp * GROUP_BYTES;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
     const int nkt = p.K / GEMM_BK;
     const int z = blockIdx.y;
     const int per = (nkt + p.splits - 1) / p.splits;
@@ -392,7 +388,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 
 template <typename T, int BM, int BN, bool CONV>
 static int launch_kg2(const GemmParams& p, hipStream_t stream) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmParams q = p;
+    int tiles;
+    xcd_partition(q, BM, BN, &tiles);
     const size_t smem = 2 * 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
     auto kern = gemm_kg2_kernel<T, BM, BN, CONV>;
     static bool attr_set = false;
@@ -400,13 +398,15 @@ static int launch_kg2(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(512), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(512), smem, stream, q);
     return check_launch("gemm_kg2_kernel");
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S, bool CONV>
 static int launch_ring(const GemmParams& p, hipStream_t stream) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmParams q = p;
+    int tiles;
+    xcd_partition(q, BM, BN, &tiles);
     const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
     auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, S, CONV>;
     static bool attr_set = false;
@@ -414,7 +414,7 @@ static int launch_ring(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * WM * WN), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * WM * WN), smem, stream, q);
     return check_launch("gemm_ring_kernel");
 }
 

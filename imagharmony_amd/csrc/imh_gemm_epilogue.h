@@ -6,6 +6,40 @@
 
 namespace imh {
 
+// XCD-aware workgroup -> tile map.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for L2
+// locality only, never for correctness).  Each XCD owns one cell of a px x py partition of the tile grid
+// (tmx x tny tiles per cell), so its private 4 MB L2 sees only M/px rows of X and N/py rows of W instead of
+// every XCD re-fetching both operands (8x fetch amplification measured with FETCH_SIZE, profiles/r01_pmc_*).
+// Returns false for the padding workgroups of ragged partitions.
+template <int BM, int BN>
+__device__ __forceinline__ bool xcd_tile(const GemmParams& p, int b, int& m0, int& n0) {
+    const int xcd = b & 7, s = b >> 3;
+    const int xi = xcd / p.py, yi = xcd - xi * p.py;
+    const int ms = s / p.tny, ns = s - ms * p.tny;
+    m0 = (xi * p.tmx + ms) * BM;
+    n0 = (yi * p.tny + ns) * BN;
+    return ms < p.tmx && m0 < p.M && n0 < p.N;
+}
+
+// host side: choose the partition that minimises the bytes the 8 L2s fetch together, py*|X| + px*|W|,
+// penalising partitions whose ragged cells launch many padding workgroups
+inline void xcd_partition(GemmParams& p, int bm, int bn, int* grid) {
+    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+    int bpx = 8, bpy = 1;
+    double best = 1e300;
+    const int cand[4][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}};
+    for (auto& c : cand) {
+        const int tmx = (tm + c[0] - 1) / c[0], tny = (tn + c[1] - 1) / c[1];
+        const double waste = (double)(tmx * c[0]) * (tny * c[1]) / ((double)tm * tn);
+        const double cost = ((double)c[1] * p.M + (double)c[0] * p.N) * waste * waste;
+        if (cost < best) { best = cost; bpx = c[0]; bpy = c[1]; }
+    }
+    p.px = bpx; p.py = bpy;
+    p.tmx = (tm + bpx - 1) / bpx;
+    p.tny = (tn + bpy - 1) / bpy;
+    *grid = 8 * p.tmx * p.tny;
+}
+
 enum : int {
     GF_GEGLU = 1,      // columns interleaved (value, gate): out[n/2] = a * gelu(g)
     GF_ACT_GELU = 2,   // exact-erf GELU on the (biased) result

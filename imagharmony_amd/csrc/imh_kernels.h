@@ -20,6 +20,8 @@ struct GemmParams {
     int flags;
     // implicit-GEMM conv3x3 (pad 1): input H x Wd (virtual size << up), output Ho x Wo
     int H, Wd, Cin, Ho, Wo, stride, up;
+    // XCD-aware tile placement (set by the launchers): the 8 XCDs form a px x py grid over the tile space
+    int px, py, tmx, tny;
 };
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
