@@ -104,8 +104,8 @@ class AttnProcessor2_0(nn.Module):
         C_ = x.shape[1]
         H = attn.heads
         wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
-        qk = ctx.gemm(x, wqk, descr="self.to_qk")                               # [M, 2C]
-        vt = ctx.gemm(wv, x, flags=L.GF_VT_PERM, descr="self.to_v^T")           # [C, M]
+        # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch
+        qk, vt = ctx.gemm_dual(dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM), descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")

@@ -30,6 +30,26 @@ int check_launch(const char* what) {
     return IMH_OK;
 }
 
+static GemmParams to_gemm(const imh_gemm_args* a) {
+    GemmParams p;
+    p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
+    p.residual = a->residual;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
+    p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
+    p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.stride = a->stride; p.up = a->up;
+    p.px = p.py = 1; p.tmx = p.tny = 0;
+    return p;
+}
+
+static int do_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, hipStream_t s) {
+    if (!a || !b || !a->X || !a->W || !a->Y || !b->X || !b->W || !b->Y) { set_error("gemm_dual: null pointer argument"); return IMH_ERR_ARG; }
+    if (a->conv || b->conv || a->dtype != b->dtype) { set_error("gemm_dual: both problems must be plain GEMMs of one dtype"); return IMH_ERR_ARG; }
+    int bm = a->bm, bn = a->bn;
+    if (bm <= 0 || bn <= 0 || bm > 128) { bm = 128; bn = 64; }
+    return gemm_dual_launch(to_gemm(a), to_gemm(b), a->dtype, bm, bn, s);
+}
+
 static int do_gemm(const imh_gemm_args* a, hipStream_t s) {
     if (!a || !a->X || !a->W || !a->Y) { set_error("gemm: null pointer argument"); return IMH_ERR_ARG; }
     GemmParams p;
@@ -111,6 +131,7 @@ struct imh_op {
         imh_norm_args norm;
         imh_ew_args ew;
         imh_small_attn_args sattn;
+        imh_gemm_args gemm2[2];
     } u;
 };
 
@@ -134,6 +155,7 @@ static int run_op(const imh_op& o, hipStream_t s) {
         }
         case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
         case IMH_OP_ATTN_SMALL: return do_attn_small(&o.u.sattn, s);
+        case IMH_OP_GEMM_DUAL: return do_gemm_dual(&o.u.gemm2[0], &o.u.gemm2[1], s);
     }
     set_error("plan: unknown op kind %d", o.kind);
     return IMH_ERR_ARG;
@@ -152,6 +174,7 @@ static size_t args_size(int kind) {
         case IMH_OP_LAYERNORM: return sizeof(imh_norm_args);
         case IMH_OP_EW: return sizeof(imh_ew_args);
         case IMH_OP_ATTN_SMALL: return sizeof(imh_small_attn_args);
+        case IMH_OP_GEMM_DUAL: return 2 * sizeof(imh_gemm_args);
     }
     return 0;
 }
@@ -168,6 +191,7 @@ int imh_debug_set(int key, int value) {
 const char* imh_last_error(void) { return g_err; }
 
 int imh_gemm(const imh_gemm_args* a, void* stream) { return do_gemm(a, (hipStream_t)stream); }
+int imh_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, void* stream) { return do_gemm_dual(a, b, (hipStream_t)stream); }
 int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
     if (!bm || !bn || !splits) { set_error("pick_config: null output"); return IMH_ERR_ARG; }
     gemm_pick_config(M, N, K, bm, bn, splits);

@@ -26,7 +26,7 @@ namespace imh {
 
 
 template <typename T, int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, const int z) {
     constexpr int FM = BM / 32;   // 16-row token fragments per wave
     constexpr int FN = BN / 32;   // 16-row weight fragments per wave
     constexpr int RX = BM / 32;   // staging rounds (32 rows per round per block)
@@ -46,11 +46,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // ---- tile coordinates; blockIdx.x walks N fastest inside an M panel so that concurrently
     //      resident blocks share the token panel in L2 ----
     int m0, n0;
-    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
+    if (!xcd_tile<BM, BN>(p, bid, m0, n0)) return;     // the whole workgroup exits together
 
     // ---- split-K range ----
     const int nkt = p.K / GEMM_BK;
-    const int z = blockIdx.y;
     const int per = (nkt + p.splits - 1) / p.splits;
     const int kt0 = z * per;
     const int kt1 = min(nkt, kt0 + per);
@@ -193,6 +192,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    gemm_body<T, BM, BN, CONV>(p, blockIdx.x, blockIdx.y);
+}
+
+// Two independent problems in ONE launch (e.g. self-attention's [Q|K] = x [Wq;Wk]^T and V^T = Wv x^T, which
+// share x): workgroups [0, grid_a) run problem a, the rest problem b.  Halves the launch count of the pair and
+// lets the two sub-chip-sized grids fill the machine together.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
+    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false>(a, blockIdx.x, 0);
+    else gemm_body<T, BM, BN, false>(b, blockIdx.x - grid_a, 0);
+}
+
 // split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
@@ -262,6 +275,44 @@ static int launch_typed(const GemmParams& p, int conv, int bm, int bn, hipStream
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;
+}
+
+template <typename T, int BM, int BN>
+static int launch_dual_tile(const GemmParams& a, const GemmParams& b, hipStream_t stream) {
+    GemmParams qa = a, qb = b;
+    int ga, gb;
+    xcd_partition(qa, BM, BN, &ga);
+    xcd_partition(qb, BM, BN, &gb);
+    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
+    hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    return check_launch("gemm_dual_kernel");
+}
+
+template <typename T>
+static int launch_dual_typed(const GemmParams& a, const GemmParams& b, int bm, int bn, hipStream_t stream) {
+    if (bm == 128 && bn == 128) return launch_dual_tile<T, 128, 128>(a, b, stream);
+    if (bm == 128 && bn == 64) return launch_dual_tile<T, 128, 64>(a, b, stream);
+    if (bm == 64 && bn == 128) return launch_dual_tile<T, 64, 128>(a, b, stream);
+    if (bm == 64 && bn == 64) return launch_dual_tile<T, 64, 64>(a, b, stream);
+    set_error("gemm_dual: unsupported tile %dx%d", bm, bn);
+    return IMH_ERR_ARG;
+}
+
+int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream) {
+    for (const GemmParams* p : {&a, &b}) {
+        if (p->K % GEMM_BK != 0 || p->K <= 0 || p->M <= 0 || p->N <= 0 || (p->ldx & 7) || (p->ldw & 7)) {
+            set_error("gemm_dual: bad shape M=%d N=%d K=%d", p->M, p->N, p->K);
+            return IMH_ERR_SHAPE;
+        }
+        if ((p->flags & GF_GEGLU) && (p->N & 15)) { set_error("geglu: N must be a multiple of 16"); return IMH_ERR_SHAPE; }
+        if (p->rowadd && p->rows_per_batch <= 0) { set_error("gemm_dual: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
+    }
+    a.splits = b.splits = 1;
+    if (((a.flags | b.flags) & GF_VT_PERM) && bn != 128) bn = 128;     // the permutation lives in 16-column groups
+    if (dtype == IMH_DT_BF16) return launch_dual_typed<bf16_t>(a, b, bm, bn, stream);
+    if (dtype == IMH_DT_F16) return launch_dual_typed<f16_t>(a, b, bm, bn, stream);
+    set_error("gemm_dual: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
 }
 
 // heuristic tile / split-K choice; overridable per call (bm/bn/splits > 0)

@@ -27,6 +27,7 @@ struct GemmParams {
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 size_t gemm_workspace_bytes(int M, int N, int splits);
 int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
+int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream);
 
 struct AttnParams {
     const void* Q;    // [B, Lq, ldq] (+ head*64 columns)

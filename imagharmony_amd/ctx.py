@@ -146,7 +146,8 @@ class Ctx:
         return bm.value, bn.value, sp.value
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
-             M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None):
+             M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
+             _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
@@ -158,6 +159,8 @@ class Ctx:
         if out is None:
             out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
         bm, bn, sp = cfg or self._config(M, N, K, 0, flags)
+        if _args_only:
+            sp = 1
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
@@ -172,9 +175,26 @@ class Ctx:
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
         es = x.element_size()
+        if _args_only:
+            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual)
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
                    keep=(x, w, out, bias, rowadd, residual), shape=(M, N, K, 0, None))
         return out
+
+    def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
+        """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch."""
+        a1, o1, f1, b1, k1 = self.gemm(_args_only=True, cfg=(cfg[0], cfg[1], 1), **g1)
+        a2, o2, f2, b2, k2 = self.gemm(_args_only=True, cfg=(cfg[0], cfg[1], 1), **g2)
+        pair = (L.GemmArgs * 2)(a1, a2)
+        if self.record:
+            rc = self.lib.imh_plan_add(self.plan, L.OP_GEMM_DUAL, C.cast(pair, C.c_void_p), 0, self.tag)
+            if rc < 0:
+                L.check(rc, "imh_plan_add")
+            self.keep.extend(t for t in k1 + k2 if t is not None)
+            self.tags.append((self.tag, L.OP_GEMM, descr, f1 + f2, b1 + b2, None))
+        else:
+            L.check(self.lib.imh_gemm_dual(C.byref(pair[0]), C.byref(pair[1]), self.stream()), descr)
+        return o1, o2
 
     def conv3x3(self, x, w, bias=None, stride=1, up=0, residual=None, rowadd=None, ldra=0, out=None, cfg=None,
                 descr="conv3x3"):

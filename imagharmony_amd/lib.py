@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libimh_hip.so")
 
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32 = 1, 2, 4, 8, 16
-OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL = 0, 1, 2, 3, 4, 5
+OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL = 0, 1, 2, 3, 4, 5, 6
 EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET = range(8)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
@@ -61,6 +61,7 @@ SYMBOLS = [
     ("imh_last_error", C.c_char_p, []),
     ("imh_debug_set", C.c_int, [C.c_int, C.c_int]),
     ("imh_gemm", C.c_int, [C.POINTER(GemmArgs), _vp]),
+    ("imh_gemm_dual", C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _vp]),
     ("imh_gemm_pick_config", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]),
     ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),

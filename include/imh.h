@@ -88,6 +88,10 @@ typedef struct imh_gemm_args {
 } imh_gemm_args;
 
 int imh_gemm(const imh_gemm_args* a, void* stream);
+/* two independent plain GEMMs of one dtype in ONE launch (a's tile config is used for both); e.g. the [Q|K]
+ * and V^T projections of a self-attention layer (attention_processor.py:292,299,300), which share x.
+ * In a plan: kind IMH_OP_GEMM_DUAL with args = imh_gemm_args[2]. */
+int imh_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, void* stream);
 int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 size_t imh_gemm_workspace_bytes(int M, int N, int splits);
 
@@ -194,7 +198,7 @@ int imh_elementwise(int op, const imh_ew_args* a, void* stream);
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
 enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4,
-                   IMH_OP_ATTN_SMALL = 5 };
+                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6 };
 
 typedef struct imh_plan imh_plan;
 
