@@ -57,6 +57,24 @@ def _packed_qk(attn, ctx):
     return cached[1]
 
 
+def fold_ln(w, norm, ctx):
+    """LayerNorm folded into the following Linear:  LN(x) W^T = rstd * (x (W*gamma)^T - mean * s) + c  with
+    s = sum_k (W*gamma)[., k] (taken from the ROUNDED folded weight, so the mean term cancels exactly) and
+    c = W beta.  Returns (W*gamma in the compute dtype, s fp32, c fp32)."""
+    g, b = norm.weight.detach().float().to(ctx.device), norm.bias.detach().float().to(ctx.device)
+    wf = w.detach().float().to(ctx.device)
+    wg = (wf * g[None, :]).to(ctx.dtype).contiguous()
+    return wg, wg.float().sum(1).contiguous(), (wf @ b).contiguous()
+
+
+def _cached(obj, name, key, make):
+    c = getattr(obj, name, None)
+    if c is None or c[0] != key:
+        c = (key, make())
+        setattr(obj, name, c)
+    return c[1]
+
+
 def _check_attn(attn, hidden_states, attention_mask):
     if attention_mask is not None:
         raise NotImplementedError("attention masks are not used on the SDXL path (attention_processor.py:283-287)")
@@ -98,14 +116,26 @@ class AttnProcessor2_0(nn.Module):
         super().__init__()
 
     # -- recorded / fused path ------------------------------------------------------------
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None):
-        """x: [B*L, C] (already layer-normed).  Returns to_out(attention(x)) (+ residual).
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None):
+        """x: [B*L, C].  Returns to_out(attention(x)) (+ residual).
+        ln = (norm module, stats [M,2]): x is the UN-normalised residual stream and LayerNorm is folded into the
+        projections; otherwise x is already layer-normed.
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
         C_ = x.shape[1]
         H = attn.heads
-        wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
+        if ln is None:
+            wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
+            g1, g2 = dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM)
+        else:
+            norm, stat = ln
+            key = (attn.to_q.weight.data_ptr(), attn.to_v.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+            fq, fv = _cached(attn, "_imh_ln_qkv", key, lambda: (
+                fold_ln(torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0), norm, ctx),
+                fold_ln(attn.to_v.weight, norm, ctx)))
+            g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(stat, fq[1], fq[2]))
+            g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(stat, fv[1], fv[2]))
         # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch
-        qk, vt = ctx.gemm_dual(dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM), descr="self.to_qk+v^T")
+        qk, vt = ctx.gemm_dual(g1, g2, descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")
@@ -161,10 +191,16 @@ class IPAttnProcessor2_0(nn.Module):
             kv.k2, kv.vt2, kv.lk2, kv.lk2_pad = project_kv(ctx, ip, _w(self.to_k_ip, ctx), _w(self.to_v_ip, ctx))
         return kv
 
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None):
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None):
         C_ = x.shape[1]
         H = attn.heads
-        q = ctx.gemm(x, _w(attn.to_q, ctx), descr="cross.to_q")
+        if ln is None:
+            q = ctx.gemm(x, _w(attn.to_q, ctx), descr="cross.to_q")
+        else:       # x is the un-normalised stream; LayerNorm folded into to_q
+            norm, stat = ln
+            key = (attn.to_q.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+            fq = _cached(attn, "_imh_ln_q", key, lambda: fold_ln(attn.to_q.weight, norm, ctx))
+            q = ctx.gemm(x, fq[0], flags=L.GF_LN_ROW, ln=(stat, fq[1], fq[2]), descr="cross.to_q")
         ao = ctx.new(B * L_, C_)
         if kv.k2 is not None:
             ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,

@@ -46,6 +46,8 @@ enum : int {
     GF_ACT_SILU = 4,
     GF_VT_PERM = 8,    // permute each 16-column group [0-3,8-11,4-7,12-15] (attention V^T layout)
     GF_OUT_F32 = 16,   // store fp32 instead of T
+    GF_LN_ROW = 32,    // folded LayerNorm, stats per row m, ln_s / ln_c per column n
+    GF_LN_COL = 64,    // folded LayerNorm, stats per column n, ln_s / ln_c per row m
 };
 
 // vector load of CNT (4 | 8 | 16) consecutive T values into floats (16-B / 8-B accesses)
@@ -82,16 +84,37 @@ __device__ __forceinline__ void stv(T* p, const float* v) {
     }
 }
 
+// Folded-LayerNorm operands that depend only on the lane's column range: fetched ONCE per lane (before the K
+// loop, so their latency hides under it) instead of once per output row in the epilogue.  Returns whether
+// `pre` (2*NV floats) is valid: row form -> s[NV] then c[NV]; column form -> (mean, rstd) pairs.
+template <int NV>
+__device__ __forceinline__ bool ln_preload(const GemmParams& p, int nb, float (&pre)[2 * NV]) {
+    if (!(p.flags & (GF_LN_ROW | GF_LN_COL)) || nb + NV > p.N) return false;
+    if (p.flags & GF_LN_ROW) {
+#pragma unroll
+        for (int q0 = 0; q0 < NV; q0 += 4) {
+            const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + q0), c4 = *(const f32x4*)(p.ln_c + nb + q0);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) { pre[q0 + e2] = s4[e2]; pre[NV + q0 + e2] = c4[e2]; }
+        }
+    } else {
+#pragma unroll
+        for (int q0 = 0; q0 < 2 * NV; q0 += 4) {
+            const f32x4 st = *(const f32x4*)(p.ln_stat + 2 * nb + q0);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) pre[q0 + e2] = st[e2];
+        }
+    }
+    return true;
+}
+
 // Epilogue of one lane: NV = 4*FN consecutive columns nb.. of row m.
 // Fast path (whole vector in range, 16-B aligned operands): vector loads/stores only.
 template <typename T, int FN>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4 * FN], int m, int nb) {
+__device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&v)[4 * FN], int m, int nb,
+                                                   const float (&lnpre)[8 * FN], const bool have_pre) {
     constexpr int NV = 4 * FN;
     constexpr int NH = NV / 2;
-    if ((p.flags & GF_VT_PERM) && FN == 4) {   // V^T key permutation: swap the 2nd and 3rd run of 4
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { float t = v[4 + r]; v[4 + r] = v[8 + r]; v[8 + r] = t; }
-    }
     const T* bias = (const T*)p.bias;
     const T* rowadd = p.rowadd ? (const T*)p.rowadd + (size_t)(m / p.rows_per_batch) * p.ldra : nullptr;
     const T* res = (const T*)p.residual;
@@ -99,6 +122,47 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4
     const bool geglu = p.flags & GF_GEGLU;
     const bool fast = (nb + NV <= N) && !(p.ldy & 7) && (!res || !(p.ldr & 7)) && (!rowadd || !(p.ldra & 7));
     float t[NV];
+    if (p.flags & (GF_LN_ROW | GF_LN_COL)) {
+        const bool whole = nb + NV <= N;
+        if (p.flags & GF_LN_ROW) {       // y = rstd_m * (acc - mean_m * s_n) + c_n
+            const float mean = p.ln_stat[2 * m], rstd = p.ln_stat[2 * m + 1];
+            if (have_pre) {              // s_n, c_n preloaded once per lane by the caller (ln_preload)
+#pragma unroll
+                for (int q = 0; q < NV; ++q) v[q] = rstd * (v[q] - mean * lnpre[q]) + lnpre[NV + q];
+            } else if (whole) {
+#pragma unroll
+                for (int q0 = 0; q0 < NV; q0 += 4) {
+                    const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + q0), c4 = *(const f32x4*)(p.ln_c + nb + q0);
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) v[q0 + e2] = rstd * (v[q0 + e2] - mean * s4[e2]) + c4[e2];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] = rstd * (v[q] - mean * p.ln_s[nb + q]) + p.ln_c[nb + q];
+            }
+        } else {                         // y = rstd_n * (acc - mean_n * s_m) + c_m
+            const float sm = p.ln_s[m], cm = p.ln_c[m];
+            if (have_pre) {              // (mean_n, rstd_n) pairs preloaded
+#pragma unroll
+                for (int q = 0; q < NV; ++q) v[q] = lnpre[2 * q + 1] * (v[q] - lnpre[2 * q] * sm) + cm;
+            } else if (whole) {
+#pragma unroll
+                for (int q0 = 0; q0 < NV; q0 += 2) {
+                    const f32x4 st = *(const f32x4*)(p.ln_stat + 2 * (nb + q0));     // (mean, rstd) x 2 columns
+                    v[q0] = st[1] * (v[q0] - st[0] * sm) + cm;
+                    v[q0 + 1] = st[3] * (v[q0 + 1] - st[2] * sm) + cm;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                    if (nb + q < N) v[q] = p.ln_stat[2 * (nb + q) + 1] * (v[q] - p.ln_stat[2 * (nb + q)] * sm) + cm;
+            }
+        }
+    }
+    if ((p.flags & GF_VT_PERM) && FN == 4) {   // V^T key permutation: swap the 2nd and 3rd run of 4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float t = v[4 + r]; v[4 + r] = v[8 + r]; v[8 + r] = t; }
+    }
     if (fast) {
         if (bias) { ldv<T, NV>(bias + nb, t);
 #pragma unroll
@@ -167,6 +231,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4
 #pragma unroll
         for (int q = 0; q < NV; ++q) if (nb + q < N) y[q] = from_f32<T>(v[q]);
     }
+}
+
+template <typename T, int FN>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, float (&v)[4 * FN], int m, int nb) {
+    const float none[8 * FN] = {};
+    epilogue_store_pre<T, FN>(p, v, m, nb, none, false);
 }
 
 }  // namespace imh

@@ -234,6 +234,57 @@ __global__ __launch_bounds__(256) void ln_kernel(const NormParams p) {
     }
 }
 
+// row statistics only (mean, rstd) -> fp32 [rows, 2]; the normalisation itself is folded into the consumer GEMM
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const NormParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int C = p.C, CL = C >> 3;
+    const T* x = (const T*)p.x + (size_t)row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < CL) {
+            v8 t = *(const v8*)(x + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = to_f32(t[e]); s += v[k][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < CL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
+    if (lane == 0) { ((float*)p.y)[2 * row] = mean; ((float*)p.y)[2 * row + 1] = rstd; }
+}
+
+int layernorm_stats_launch(const NormParams& p, int dtype, hipStream_t stream) {
+    if (p.C % 8 || p.C > 4096 || p.rows <= 0) { set_error("layernorm_stats: unsupported C=%d rows=%d", p.C, p.rows); return IMH_ERR_SHAPE; }
+    dim3 grid((p.rows + 3) / 4);
+    const int cl = p.C >> 3;
+#define IMH_LNS(TT) do { if (cl <= 128) hipLaunchKernelGGL((ln_stats_kernel<TT, 2>), grid, dim3(256), 0, stream, p); \
+        else if (cl <= 256) hipLaunchKernelGGL((ln_stats_kernel<TT, 4>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((ln_stats_kernel<TT, 8>), grid, dim3(256), 0, stream, p); } while (0)
+    if (dtype == IMH_DT_BF16) IMH_LNS(bf16_t);
+    else if (dtype == IMH_DT_F16) IMH_LNS(f16_t);
+    else { set_error("layernorm_stats: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+#undef IMH_LNS
+    return check_launch("ln_stats_kernel");
+}
+
 template <typename T>
 static int ln_typed(const NormParams& p, hipStream_t stream) {
     const int cl = p.C >> 3;

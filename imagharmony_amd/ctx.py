@@ -120,6 +120,8 @@ class Ctx:
             rc = self.lib.imh_layernorm(C.byref(args), s)
         elif kind == L.OP_ATTN_SMALL:
             rc = self.lib.imh_attention_small(C.byref(args), s)
+        elif kind == L.OP_LN_STATS:
+            rc = self.lib.imh_layernorm_stats(C.byref(args), s)
         else:
             rc = self.lib.imh_elementwise(ew_op, C.byref(args), s)
         L.check(rc, descr or f"op kind {kind}")
@@ -147,7 +149,7 @@ class Ctx:
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             _args_only=False):
+             ln=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
@@ -164,6 +166,8 @@ class Ctx:
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
+        if ln is not None:           # (stat [rows,2], s, c) fp32; the caller sets GF_LN_ROW / GF_LN_COL in flags
+            a.ln_stat, a.ln_s, a.ln_c = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr()
         a.M, a.N, a.K = M, N, K
         a.ldx = ldx if ldx is not None else x.stride(0)
         a.ldw = ldw if ldw is not None else w.stride(0)
@@ -176,9 +180,9 @@ class Ctx:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
         es = x.element_size()
         if _args_only:
-            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual)
+            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + tuple(ln or ())
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual), shape=(M, N, K, 0, None))
+                   keep=(x, w, out, bias, rowadd, residual) + tuple(ln or ()), shape=(M, N, K, 0, None))
         return out
 
     def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
@@ -286,6 +290,19 @@ class Ctx:
         es = x.element_size()
         self._emit(L.OP_LAYERNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=2.0 * es * x.numel(),
                    keep=(x, out, gamma, beta))
+        return out
+
+    def layernorm_stats(self, x, eps, descr="ln_stats"):
+        """fp32 [rows, 2] (mean, rstd) of x's rows; the normalisation is folded into the consumer GEMM (ln=...)"""
+        self._chk(x, descr + ".x")
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        out = self.new(rows, 2, dtype=torch.float32)
+        a = L.NormArgs()
+        a.x, a.y = x.data_ptr(), out.data_ptr()
+        a.rows, a.C, a.eps, a.dtype = rows, Cc, eps, self.dt
+        self._emit(L.OP_LN_STATS, a, descr=descr, flops=4.0 * x.numel(), nbytes=1.0 * x.element_size() * x.numel(),
+                   keep=(x, out))
         return out
 
     # ------------------------------------------------------------------ elementwise

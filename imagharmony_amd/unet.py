@@ -29,6 +29,11 @@ from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _w
 from .ctx import Ctx
 
 
+# Fold BasicTransformerBlock.norm1/2/3 into the consumer GEMMs (exact algebra, tested).  Measured on MI355X at
+# batch 1 it is a wash (row-stats kernels 1.4 ms + slower epilogues vs 2.2 ms of LayerNorm kernels), so it is off.
+FOLD_LAYERNORM = False
+
+
 @dataclass
 class UNetConfig:
     in_channels: int = 4
@@ -146,14 +151,37 @@ class GEGLU(nn.Module):
         return c[1], c[2]
 
 
+def _geglu_packed_ln(self, ctx, norm):
+    """GEGLU projection with LayerNorm folded in (see attention_processor.fold_ln), rows interleaved (value, gate)."""
+    from .attention_processor import fold_ln
+    key = (self.proj.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    c = getattr(self, "_imh_packed_ln", None)
+    if c is None or c[0] != key:
+        wg, s, cc = fold_ln(self.proj.weight, norm, ctx)
+        inner = wg.shape[0] // 2
+        il = lambda t: torch.stack([t[:inner], t[inner:]], 1).reshape((2 * inner,) + tuple(t.shape[1:])).contiguous()
+        b = self.proj.bias.detach().to(device=ctx.device, dtype=ctx.dtype)
+        c = (key, il(wg), il(b), il(s), il(cc))
+        self._imh_packed_ln = c
+    return c[1], c[2], c[3], c[4]
+
+
+GEGLU.packed_ln = _geglu_packed_ln
+
+
 class FeedForward(nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), Dropout(), Linear(dim * 4, dim)])
 
-    def emit(self, ctx, x, residual):
-        w1, b1 = self.net[0].packed(ctx)
-        g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU, descr="ff.geglu")
+    def emit(self, ctx, x, residual, ln=None):
+        if ln is None:
+            w1, b1 = self.net[0].packed(ctx)
+            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU, descr="ff.geglu")
+        else:       # x un-normalised, LayerNorm folded into the (interleaved) GEGLU projection
+            norm, stat = ln
+            w1, b1, s1, c1 = self.net[0].packed_ln(ctx, norm)
+            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU | L.GF_LN_ROW, ln=(stat, s1, c1), descr="ff.geglu")
         out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out")
         ctx.free(g)
         return out
@@ -178,6 +206,19 @@ class BasicTransformerBlock(nn.Module):
         if not hasattr(p1, "emit") or not hasattr(p2, "emit"):
             raise L.ImhError("a non-HIP attention processor is installed; the fused forward needs "
                              "imagharmony_amd.attention_processor processors")
+        if FOLD_LAYERNORM and isinstance(p1, AttnProcessor2_0) and isinstance(p2, IPAttnProcessor2_0):
+            # LayerNorm never materialises: row statistics only, normalisation folded into the consumer GEMMs
+            s1 = ctx.layernorm_stats(h, self.norm1.eps, descr="norm1.stats")
+            h1 = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=(self.norm1, s1))
+            ctx.free(s1); ctx.free(h)
+            s2 = ctx.layernorm_stats(h1, self.norm2.eps, descr="norm2.stats")
+            h2 = p2.emit(ctx, self.attn2, h1, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab,
+                         ln=(self.norm2, s2))
+            ctx.free(s2); ctx.free(h1)
+            s3 = ctx.layernorm_stats(h2, self.norm3.eps, descr="norm3.stats")
+            h3 = self.ff.emit(ctx, h2, residual=h2, ln=(self.norm3, s3))
+            ctx.free(s3); ctx.free(h2)
+            return h3
         n = _ln(ctx, self.norm1, h, "norm1")
         h1 = p1.emit(ctx, self.attn1, n, B, L_, residual=h)
         ctx.free(n); ctx.free(h)

@@ -50,7 +50,9 @@ enum imh_gemm_flags {
     IMH_GF_ACT_GELU = 2,  /* exact-erf GELU (resampler.py:18) */
     IMH_GF_ACT_SILU = 4,  /* SiLU (TimestepEmbedding) */
     IMH_GF_VT_PERM = 8,   /* write the attention V^T key permutation (see imh_attention) */
-    IMH_GF_OUT_F32 = 16   /* fp32 output */
+    IMH_GF_OUT_F32 = 16,  /* fp32 output */
+    IMH_GF_LN_ROW = 32,   /* folded LayerNorm, statistics per output row m */
+    IMH_GF_LN_COL = 64    /* folded LayerNorm, statistics per output column n (swapped-operand V^T form) */
 };
 
 /* ---- dense contraction ------------------------------------------------------------------
@@ -76,6 +78,13 @@ typedef struct imh_gemm_args {
     const void* bias;
     const void* rowadd;
     const void* residual;
+    /* LayerNorm folded into the contraction (IMH_GF_LN_ROW: X rows are the un-normalised tokens; IMH_GF_LN_COL:
+     * W rows are).  With W pre-scaled by gamma:  y = rstd * (acc - mean * ln_s) + ln_c  (exact algebra of
+     * LN(x) W^T; BasicTransformerBlock.norm1/2/3 never materialise).  ln_stat = [rows, 2] fp32 (mean, rstd) from
+     * imh_layernorm_stats; ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k W[.,k] (fp32). */
+    const float* ln_stat;
+    const float* ln_s;
+    const float* ln_c;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -166,6 +175,8 @@ typedef struct imh_norm_args {
 int imh_groupnorm(const imh_norm_args* a, void* stream);
 size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int imh_layernorm(const imh_norm_args* a, void* stream);
+/* row statistics only: y = fp32 [rows, 2] (mean, rstd); consumed by imh_gemm with IMH_GF_LN_ROW / _COL */
+int imh_layernorm_stats(const imh_norm_args* a, void* stream);
 
 /* ---- small fused elementwise kernels (see csrc/elementwise.hip for the field meaning) ---- */
 enum imh_ew_op {
@@ -198,7 +209,7 @@ int imh_elementwise(int op, const imh_ew_args* a, void* stream);
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
 enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4,
-                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6 };
+                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6, IMH_OP_LN_STATS = 7 };
 
 typedef struct imh_plan imh_plan;
 

@@ -312,3 +312,30 @@ def test_errors_are_reported_not_thrown(L):
     x, w = rnd(64, 96, dtype=torch.bfloat16, seed=1), rnd(64, 96, dtype=torch.bfloat16, seed=2)
     with pytest.raises(L.ImhError, match="multiple of 64"):
         ctx.gemm(x, w)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_folded_layernorm(L, dtype):
+    """LN(x) W^T through the folded form (row statistics + gamma-scaled weights) in both orientations,
+    against F.layer_norm + matmul in fp32, with a large row mean (the cancellation case)."""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    M, N, K = 192, 256, 128
+    x = (rnd(M, K, dtype=dtype, seed=1) * 1.5 + 3.0).contiguous()       # |mean| / std = 2
+    w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+    norm = torch.nn.LayerNorm(K, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3)))
+        norm.bias.copy_(0.3 * torch.randn(K, generator=torch.Generator().manual_seed(4)))
+    ref = F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()
+    wg, s, c = fold_ln(w, norm, ctx)
+    stat = ctx.layernorm_stats(x, 1e-5)
+    xr = x.float()
+    assert torch.allclose(stat[:, 0], xr.mean(1), atol=1e-4) and torch.allclose(stat[:, 1], (xr.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(stat, s, c))
+    assert_close(y, ref.to(DEV), dtype, "folded LN (row form)", k=6.0)
+    yt = ctx.gemm(wg, x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(stat, s, c))      # [N, M] = (LN(x) W^T)^T, V^T layout
+    assert_close(vt_unpermute(yt), ref.t().to(DEV), dtype, "folded LN (col form)", k=6.0)
+    y2, yt2 = ctx.gemm_dual(dict(x=x, w=wg, flags=L.GF_LN_ROW, ln=(stat, s, c)),
+                            dict(x=wg, w=x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(stat, s, c)))
+    assert torch.equal(y2, y) and torch.equal(yt2, ctx.gemm(wg, x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(stat, s, c), cfg=(128, 128, 1)))
