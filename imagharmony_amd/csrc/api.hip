@@ -39,6 +39,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
     p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.stride = a->stride; p.up = a->up;
     p.px = p.py = 1; p.tmx = p.tny = 0;
+    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return p;
 }
 
@@ -84,6 +85,7 @@ static int do_attn(const imh_attn_args* a, hipStream_t s) {
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.Lk_pad = a->Lk_pad; p.Lk2 = a->Lk2; p.Lk2_pad = a->Lk2_pad;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldk2 = a->ldk2; p.ldvt2 = a->ldvt2; p.ldo = a->ldo;
     p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step; p.ablate = 0;
+    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return attention_launch(p, a->dtype, s);
 }
 
@@ -100,6 +102,7 @@ static NormParams to_norm(const imh_norm_args* a) {
     NormParams p;
     p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.partial = a->partial;
     p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.rows = a->rows; p.eps = a->eps; p.silu = a->silu;
+    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return p;
 }
 

@@ -32,8 +32,10 @@ constexpr float NEG_BIG = -1.0e30f;
 // NW waves per workgroup (32 queries each).  The grid is (ceil(Lq / (32 NW)), H, B): NW is picked by the
 // launcher so that the number of workgroups is a multiple of what the chip holds at once (SDXL: L=4096 ->
 // NW=2, L=1024 -> NW=1, both 1280 workgroups = 5 per CU), instead of 1.25 "rounds" of 4-wave workgroups.
-template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : (NW == 2 ? 3 : 2))) void attn_kernel(const AttnParams p) {
+// NPASS = 1: single key set (self-attention, text-only cross-attention): no second accumulator, lower register
+// pressure -> 3 workgroups per CU instead of 2.  NPASS = 2: text + image-prompt key sets.
+template <typename T, int NW, int NPASS>
+__global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn_kernel(const AttnParams p) {
     constexpr int RND = 8 / NW;              // staging rounds: NW*8 rows per round, 64 rows per tile
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -65,10 +67,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : (NW == 2 ? 3 : 2))) void at
 #pragma unroll
         for (int r = 0; r < 16; ++r) fin[dt][r] = 0.f;
 
-    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
         const T* Kp = (const T*)(pass == 0 ? p.K : p.K2);
         const T* Vp = (const T*)(pass == 0 ? p.Vt : p.Vt2);
-        if (pass == 1 && Kp == nullptr) break;
         const int Lk = pass == 0 ? p.Lk : p.Lk2;
         const int Lkp = pass == 0 ? p.Lk_pad : p.Lk2_pad;
         const int ldk = pass == 0 ? p.ldk : p.ldk2;
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : (NW == 2 ? 3 : 2))) void at
                 *(v4*)(op + dt * 32 + rg * 8) = o4;
             }
     }
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                  gridDim.x * gridDim.y * gridDim.z, tid, 64 * NW);
 }
 
 // ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
@@ -286,7 +290,8 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     int nw = g_attn_force_nw;
     if (nw != 1 && nw != 2 && nw != 4) nw = 4;
     dim3 grid((p.Lq + 32 * nw - 1) / (32 * nw), p.H, p.B);
-#define IMH_ATT_LAUNCH(TT, NWV) hipLaunchKernelGGL((attn_kernel<TT, NWV>), grid, dim3(64 * NWV), 0, stream, p)
+#define IMH_ATT_LAUNCH(TT, NWV) do { if (p.K2) hipLaunchKernelGGL((attn_kernel<TT, NWV, 2>), grid, dim3(64 * NWV), 0, stream, p); \
+        else hipLaunchKernelGGL((attn_kernel<TT, NWV, 1>), grid, dim3(64 * NWV), 0, stream, p); } while (0)
     if (dtype == IMH_DT_BF16) { if (nw == 4) IMH_ATT_LAUNCH(bf16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(bf16_t, 2); else IMH_ATT_LAUNCH(bf16_t, 1); }
     else { if (nw == 4) IMH_ATT_LAUNCH(f16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(f16_t, 2); else IMH_ATT_LAUNCH(f16_t, 1); }
 #undef IMH_ATT_LAUNCH

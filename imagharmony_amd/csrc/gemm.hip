@@ -46,7 +46,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     // ---- tile coordinates; blockIdx.x walks N fastest inside an M panel so that concurrently
     //      resident blocks share the token panel in L2 ----
     int m0, n0;
-    if (!xcd_tile<BM, BN>(p, bid, m0, n0)) return;     // the whole workgroup exits together
+    if (!xcd_tile<BM, BN>(p, bid, m0, n0)) {           // padding workgroup of a ragged partition: only prefetches
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, 8 * p.tmx * p.tny, threadIdx.x, 256);
+        return;
+    }
 
     // ---- split-K range ----
     const int nkt = p.K / GEMM_BK;
@@ -190,6 +193,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
             epilogue_store<T, FN>(p, v, m, nb);
         }
     }
+    if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, 8 * p.tmx * p.tny, tid, 256);
 }
 
 template <typename T, int BM, int BN, bool CONV>

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_ring_kernel(const GemmPa
             epilogue_store<T, FN>(p, v, m, nb);
         }
     }
+    if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
     };
     if (grp == 0) finish(std::integral_constant<int, 0>{});
     else finish(std::integral_constant<int, 1>{});
+    if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, blockDim.x);
 }
 
 template <typename T, int BM, int BN, bool CONV>

@@ -49,6 +49,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
 // the main loops carry no bounds branches
 static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];   // one copy per translation unit
 
+// Tail prefetch: before a workgroup exits it touches its slice (one dword per 128-B line) of the NEXT kernel's
+// weight matrix, pulling it from HBM into L2 / Infinity Cache while the rest of this kernel is still running.
+// Every layer's weights are read exactly once per UNet forward (5 GB per forward), so without this each GEMM
+// starts on cold HBM lines (+2..13 us per launch measured, tools/cold_weights.py).  Purely a cache hint.
+__device__ __forceinline__ void tail_prefetch(const void* ptr, unsigned bytes, unsigned bid, unsigned nblocks,
+                                              unsigned tid, unsigned nthreads) {
+    if (!ptr) return;
+    const unsigned per = (((bytes + nblocks - 1) / nblocks) + 127u) & ~127u;
+    const unsigned s0 = bid * per;
+    const unsigned s1 = min(bytes, s0 + per);
+    for (unsigned o = s0 + tid * 128u; o < s1; o += nthreads * 128u)
+        (void)*(const volatile unsigned*)((const unsigned char*)ptr + o);
+}
+
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }

@@ -26,6 +26,8 @@ struct GemmParams {
     int H, Wd, Cin, Ho, Wo, stride, up;
     // XCD-aware tile placement (set by the launchers): the 8 XCDs form a px x py grid over the tile space
     int px, py, tmx, tny;
+    const void* pf_ptr;    // next kernel's weights (tail prefetch), or null
+    unsigned pf_bytes;
 };
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
@@ -49,6 +51,8 @@ struct AttnParams {
     const float* scale2_tab;  // optional per-step table of IP scales, indexed by *step
     const int* step;
     int ablate;               // tuning only
+    const void* pf_ptr;       // next kernel's weights (tail prefetch), or null
+    unsigned pf_bytes;
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
@@ -72,6 +76,8 @@ struct NormParams {
     int rows;         // layer norm: rows
     float eps;
     int silu;
+    const void* pf_ptr;   // next kernel's weights (tail prefetch), or null
+    unsigned pf_bytes;
 };
 int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream);
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
     typedef typename Vec<T>::v8 v8;
     __shared__ float mean_s[64], rstd_s[64];
     __shared__ double part_s[16][64], part_q[16][64];
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, GN_THREADS);
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
     const int b = blockIdx.y, blk = blockIdx.x;
@@ -174,6 +175,7 @@ template <typename T, int NCH, int ROWS>
 __global__ __launch_bounds__(256) void ln_kernel(const NormParams p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63;
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, threadIdx.x, 256);   // fire-and-forget, overlaps the row loads
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
     if (row0 >= p.rows) return;
     const int C = p.C, CL = C >> 3;

@@ -50,6 +50,8 @@ class Ctx:
         self._ws = None
         self.tuning = _load_tuning()
         self.captured = False
+        self._ops = []          # recorded (kind, ctypes args, cold tensors) for the weight-prefetch pass
+        self._pf_done = False
 
     # ------------------------------------------------------------------ memory
     def new(self, *shape, dtype=None):
@@ -108,6 +110,7 @@ class Ctx:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(k for k in keep if k is not None)
             self.tags.append((self.tag, kind, descr, flops, nbytes, shape))
+            self._ops.append((kind, args, self._cold(keep) if kind == L.OP_GEMM else []))
             return
         s = self.stream()
         if kind == L.OP_GEMM:
@@ -196,6 +199,7 @@ class Ctx:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(t for t in k1 + k2 if t is not None)
             self.tags.append((self.tag, L.OP_GEMM, descr, f1 + f2, b1 + b2, None))
+            self._ops.append((L.OP_GEMM_DUAL, pair, self._cold(k1[:2] + k2[:2])))
         else:
             L.check(self.lib.imh_gemm_dual(C.byref(pair[0]), C.byref(pair[1]), self.stream()), descr)
         return o1, o2
@@ -330,12 +334,51 @@ class Ctx:
         return self.ew(L.EW_CONCAT, out, a=a, b=b, n=pix, i=(c1, c2, 0, 0, 0, 0), descr=descr,
                        nbytes=2.0 * out.numel() * out.element_size())
 
+    # ------------------------------------------------------------------ weight prefetch
+    def _cold(self, tensors):
+        """operands that are parameters (not pool-owned activations) and big enough to matter: every layer's
+        weights are read once per forward, i.e. always from HBM unless a previous kernel prefetches them"""
+        out = []
+        for t in tensors[:2]:
+            if t is None or t.numel() * t.element_size() < (256 << 10):
+                continue
+            if t.untyped_storage().data_ptr() in self._bases:
+                continue
+            out.append((t.data_ptr(), min(t.numel() * t.element_size(), 0xFFFFFFF0)))
+        return out
+
+    def finalize_prefetch(self):
+        """Give every recorded launch the weights of the launch that follows it (tail_prefetch in the kernels):
+        a cold weight matrix goes to the nearest earlier op (up to 3 back) whose prefetch slot is still free."""
+        if self._pf_done or not self.record:
+            return
+        self._pf_done = True
+        can = (L.OP_GEMM, L.OP_ATTN, L.OP_LAYERNORM, L.OP_GROUPNORM, L.OP_GEMM_DUAL)
+        taken = set()
+        for j, (kind, args, cold) in enumerate(self._ops):
+            for (ptr, nb) in cold:
+                # nearest earlier launch with a free slot (measured better than handing big matrices to a longer,
+                # earlier kernel: 27.0 vs 27.3 ms per forward)
+                for i in range(j - 1, max(j - 4, -1), -1):
+                    if i in taken or self._ops[i][0] not in can:
+                        continue
+                    a = self._ops[i][1]
+                    tgt = a[0] if self._ops[i][0] == L.OP_GEMM_DUAL else a
+                    tgt.pf_ptr, tgt.pf_bytes = ptr, nb
+                    ref = C.cast(a, C.c_void_p) if self._ops[i][0] == L.OP_GEMM_DUAL else C.byref(a)
+                    L.check(self.lib.imh_plan_update(self.plan, i, ref), "imh_plan_update")
+                    taken.add(i)
+                    break
+        return len(taken)
+
     # ------------------------------------------------------------------ plans
     def run(self):
+        self.finalize_prefetch()
         L.check(self.lib.imh_plan_run(self.plan, self.stream()), "imh_plan_run")
 
     def capture(self):
         """Capture the recorded plan into a hipGraph (needs a non-default stream)."""
+        self.finalize_prefetch()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -350,6 +393,7 @@ class Ctx:
             self.run()
 
     def time_ops(self):
+        self.finalize_prefetch()
         n = self.lib.imh_plan_size(self.plan)
         ms = (C.c_float * n)()
         L.check(self.lib.imh_plan_time_ops(self.plan, self.stream(), ms, n), "imh_plan_time_ops")

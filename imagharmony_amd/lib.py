@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
                 ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("stride", _i32), ("up", _i32),
-                ("dtype", _i32), ("conv", _i32), ("bm", _i32), ("bn", _i32)]
+                ("dtype", _i32), ("conv", _i32), ("bm", _i32), ("bn", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
 
 class AttnArgs(C.Structure):
@@ -33,7 +33,8 @@ class AttnArgs(C.Structure):
                 ("B", _i32), ("H", _i32), ("Lq", _i32), ("Lk", _i32), ("Lk_pad", _i32), ("Lk2", _i32),
                 ("Lk2_pad", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldvt", _i32), ("ldk2", _i32), ("ldvt2", _i32), ("ldo", _i32),
-                ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32)]
+                ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32),
+                ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
 
 class SmallAttnArgs(C.Structure):
@@ -45,7 +46,7 @@ class SmallAttnArgs(C.Structure):
 class NormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("partial", _vp),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("rows", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32)]
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
 
 class EwArgs(C.Structure):

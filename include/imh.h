@@ -94,6 +94,9 @@ typedef struct imh_gemm_args {
     int32_t dtype;
     int32_t conv;
     int32_t bm, bn;
+    /* cache hint: the NEXT launch's weight matrix; exiting workgroups touch it (HBM -> L2 / Infinity Cache) */
+    const void* pf_ptr;
+    uint32_t pf_bytes;
 } imh_gemm_args;
 
 int imh_gemm(const imh_gemm_args* a, void* stream);
@@ -133,6 +136,8 @@ typedef struct imh_attn_args {
                                 custom_pipelines.py:326-329, without re-recording the plan) */
     const int32_t* step;
     int32_t dtype;
+    const void* pf_ptr;    /* tail prefetch of the next launch's weights (cache hint) */
+    uint32_t pf_bytes;
 } imh_attn_args;
 
 int imh_attention(const imh_attn_args* a, void* stream);
@@ -170,6 +175,8 @@ typedef struct imh_norm_args {
     float eps;
     int32_t silu;
     int32_t dtype;
+    const void* pf_ptr;    /* tail prefetch of the next launch's weights (cache hint) */
+    uint32_t pf_bytes;
 } imh_norm_args;
 
 int imh_groupnorm(const imh_norm_args* a, void* stream);
