@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--ip-tokens", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=1024)
+    ap.add_argument("--in-flight", type=int, default=1, help="PNS candidates in flight per GPU (one HIP stream each, batch 1 "
+                    "each); 1 = BASELINE.json configs[1] exactly")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
                     "single-GPU testing of the multi-rank control path)")
     return ap.parse_args()
@@ -144,6 +146,28 @@ def main():
     lat_shape = (1, 4, a.res // 8, a.res // 8)
     noises = [pns.seed_latents(i * world + rank, lat_shape).to(device) for i in range(a.warmup + a.steps)]
 
+    def run_concurrent(k, n_steps, n_warm):
+        """k candidates in flight on this GPU: k engines (shared weights + conditioning), one stream each"""
+        engs = [eng] + [eng.fork() for _ in range(k - 1)]
+        streams = [torch.cuda.Stream(device) for _ in range(k)]
+        zs = [pns.seed_latents(1000 + j, lat_shape).to(device) for j in range(k)]
+        def one_round():
+            cur = torch.cuda.current_stream(device)
+            for e, s, z in zip(engs, streams, zs):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    e.denoise(z)
+            for s in streams:
+                cur.wait_stream(s)
+        for _ in range(n_warm):
+            one_round()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_round()
+        torch.cuda.synchronize(device)
+        return k * n_steps / (time.perf_counter() - t0)
+
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
@@ -198,6 +222,11 @@ def main():
                          "algorithmic_tflop_per_step": g_fl / 1e12,
                          "whole_forward_tflops": tot_fl / (dt / a.steps / a.denoise_steps) / 1e12},
         }
+        if world == 1 and a.in_flight > 1:
+            # extra, NOT the headline: several batch-1 candidates in flight on the one GPU (what PNS does with N > n_gpus)
+            res["concurrent_candidates"] = {"in_flight": a.in_flight, "images_per_sec": run_concurrent(a.in_flight, 2, 1),
+                                            "note": "independent batch-1 denoises on separate HIP streams sharing weights and "
+                                                    "conditioning; same arithmetic per image as `value`"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_res, a.ip_tokens, a.denoise_steps)

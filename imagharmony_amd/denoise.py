@@ -76,6 +76,21 @@ class DenoiseEngine:
         self.init_noise_sigma = float(tab["init_noise_sigma"])
         self.plan = None                         # table pointers changed
 
+    def fork(self):
+        """A second engine on the SAME weights and the SAME conditioning (K/V caches, aug_emb) with its own latents,
+        step counter, activation buffers and plan: lets several PNS candidates be in flight on one GPU (one HIP
+        stream each), so that kernels of independent candidates fill the CUs a batch-1 kernel leaves idle."""
+        e = DenoiseEngine(self.unet, self.device, self.dtype, self.use_graph)
+        for k in ("do_cfg", "guidance", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx"):
+            setattr(e, k, getattr(self, k))
+        st = StepState()
+        src = self.st
+        st.aug_emb, st.kv = src.aug_emb, src.kv                      # shared, read-only during denoising
+        st.t_table, st.coef_tab, st.in_scale_tab, st.ip_scale_tab = src.t_table, src.coef_tab, src.in_scale_tab, src.ip_scale_tab
+        st.step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        e.st = st
+        return e
+
     def _record(self):
         st = self.st
         if st.latents is None or tuple(st.latents.shape) != (self.S, 4, self.H, self.W):
