@@ -200,9 +200,19 @@ def main():
         ms = [min(x, y) for x, y in zip(ms, rec.time_ops())]
         g_fl = sum(t[3] for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
         g_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
+        g_by = sum(t[4] for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
         n_g = sum(1 for t in rec.tags if t[1] == L.OP_GEMM)
         tot_fl = sum(t[3] for t in rec.tags)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the family from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
+        traffic, traffic_src = None, None
+        try:
+            pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")
+            traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_hbm_traffic_final.json (rocprofv3 --pmc, same command with --denoise-steps 4)"
+        except (OSError, KeyError, ValueError):
+            pass
         images = a.steps * world
         res = {
             "metric": "1024^2 SDXL images/sec (30 DDIM steps, PNS N seeds)" if a.res == 1024 and a.denoise_steps == 30
@@ -216,7 +226,8 @@ def main():
                        "ms_per_unet_forward": dt / a.steps / a.denoise_steps * 1e3,
                        "tflop_per_unet_forward": tot_fl / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": None,
+                         "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g_by / n_g,
                          "kernel": "imh::gemm_kernel (Linear + implicit-GEMM conv3x3 family)",
                          "launches_per_step": n_g, "avg_launch_us": g_ms / n_g * 1e3,
                          "algorithmic_tflop_per_step": g_fl / 1e12,

@@ -188,6 +188,7 @@ int imh_abi_version(void) { return IMH_ABI_VERSION; }
 int imh_debug_set(int key, int value) {
     if (key == 0) { g_attn_force_nw = value; return IMH_OK; }
     if (key == 1) { g_attn_ablate = value; return IMH_OK; }
+    if (key == 2) { g_xcd_mode = value; return IMH_OK; }
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;
 }

@@ -24,6 +24,8 @@
 
 namespace imh {
 
+int g_xcd_mode = 0;
+
 
 template <typename T, int BM, int BN, bool CONV>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, const int z) {
@@ -47,7 +49,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     //      resident blocks share the token panel in L2 ----
     int m0, n0;
     if (!xcd_tile<BM, BN>(p, bid, m0, n0)) {           // padding workgroup of a ragged partition: only prefetches
-        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, 8 * p.tmx * p.tny, threadIdx.x, 256);
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, gridDim.x, threadIdx.x, 256);
         return;
     }
 
@@ -193,7 +195,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
             epilogue_store<T, FN>(p, v, m, nb);
         }
     }
-    if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, 8 * p.tmx * p.tny, tid, 256);
+    if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, gridDim.x, tid, 256);
 }
 
 template <typename T, int BM, int BN, bool CONV>

@@ -13,6 +13,11 @@ namespace imh {
 // Returns false for the padding workgroups of ragged partitions.
 template <int BM, int BN>
 __device__ __forceinline__ bool xcd_tile(const GemmParams& p, int b, int& m0, int& n0) {
+    if (p.px == 0) {                      // legacy row-major tile order (tuning / A-B only)
+        m0 = (b / p.tny) * BM;
+        n0 = (b % p.tny) * BN;
+        return m0 < p.M;
+    }
     const int xcd = b & 7, s = b >> 3;
     const int xi = xcd / p.py, yi = xcd - xi * p.py;
     const int ms = s / p.tny, ns = s - ms * p.tny;
@@ -23,8 +28,10 @@ __device__ __forceinline__ bool xcd_tile(const GemmParams& p, int b, int& m0, in
 
 // host side: choose the partition that minimises the bytes the 8 L2s fetch together, py*|X| + px*|W|,
 // penalising partitions whose ragged cells launch many padding workgroups
+// g_xcd_mode (imh_kernels.h): 0 auto, 1 legacy row-major, 2..5 force (8,1) (4,2) (2,4) (1,8)   (imh_debug_set key 2)
 inline void xcd_partition(GemmParams& p, int bm, int bn, int* grid) {
     const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+    if (g_xcd_mode == 1) { p.px = 0; p.py = 1; p.tmx = tm; p.tny = tn; *grid = tm * tn; return; }
     int bpx = 8, bpy = 1;
     double best = 1e300;
     const int cand[4][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}};
@@ -34,6 +41,7 @@ inline void xcd_partition(GemmParams& p, int bm, int bn, int* grid) {
         const double cost = ((double)c[1] * p.M + (double)c[0] * p.N) * waste * waste;
         if (cost < best) { best = cost; bpx = c[0]; bpy = c[1]; }
     }
+    if (g_xcd_mode >= 2 && g_xcd_mode <= 5) { bpx = cand[g_xcd_mode - 2][0]; bpy = cand[g_xcd_mode - 2][1]; }
     p.px = bpx; p.py = bpy;
     p.tmx = (tm + bpx - 1) / bpx;
     p.tny = (tn + bpy - 1) / bpy;

@@ -56,6 +56,7 @@ struct AttnParams {
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
+extern int g_xcd_mode;
 extern int g_attn_ablate;
 
 struct SmallAttnParams {

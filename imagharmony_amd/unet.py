@@ -474,6 +474,24 @@ class UNet2DConditionModel(nn.Module):
                 p.fill_(1.0)
         return self
 
+    # ---- checkpoints (the on-disk format either side of the path) ----
+    @classmethod
+    def from_safetensors(cls, path, cfg: "UNetConfig" = None, device="cpu", dtype=None):
+        """Load a diffusers-format SDXL UNet checkpoint (``diffusion_pytorch_model.safetensors``): the key schema is
+        the one this module keeps, so this is a strict ``load_state_dict``."""
+        from safetensors.torch import load_file
+        sd = load_file(path, device="cpu")
+        m = cls(cfg)
+        own = m.state_dict()
+        extra = [k for k in sd if k not in own]
+        missing = [k for k in own if k not in sd and ".processor." not in k]
+        if extra or missing:
+            raise KeyError(f"checkpoint / model key mismatch: {len(missing)} missing (e.g. {missing[:3]}), "
+                           f"{len(extra)} unexpected (e.g. {extra[:3]})")
+        m.load_state_dict(sd, strict=False)
+        m = m.to(device)
+        return m.to(dtype) if dtype is not None else m
+
     # ---- packed / stacked weights ----
     def _temb_stack(self, ctx):
         key = (ctx.dtype, str(ctx.device))

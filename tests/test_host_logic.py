@@ -119,3 +119,28 @@ def test_unet_recording_dry_run_tiny():
     assert kinds.count(1) == n_prep * 0 + 2 * n_blocks          # one self + one cross attention per block
     with pytest.raises(Exception):
         ctx.run()
+
+
+def test_unet_checkpoint_roundtrip_with_oracle_schema(tmp_path):
+    """a diffusers-schema safetensors file written from the ORACLE UNet loads strictly into the HIP UNet holder
+    (same key schema), and the IP-adapter state dict keeps the reference's '<idx>.to_k_ip.weight' keys"""
+    from safetensors.torch import save_file
+    from imagharmony_amd.ip_adapter import install_ip_processors
+    from imagharmony_amd.unet import UNet2DConditionModel, UNetConfig
+    from oracle.detfill import det_fill
+    from oracle.sdxl_unet import UNet2DConditionModel as OracleUNet, tiny_config
+    ocfg = tiny_config()
+    ou = det_fill(OracleUNet(ocfg), 5)
+    path = str(tmp_path / "unet.safetensors")
+    save_file({k: v.contiguous() for k, v in ou.state_dict().items()}, path)
+    cfg = UNetConfig(**{k: getattr(ocfg, k) for k in UNetConfig.__dataclass_fields__})
+    hu = UNet2DConditionModel.from_safetensors(path, cfg)
+    for k, v in ou.state_dict().items():
+        assert torch.equal(hu.state_dict()[k], v), k
+    procs = install_ip_processors(hu, num_tokens=4, dtype=torch.float32)
+    ks = list(torch.nn.ModuleList(hu.attn_processors.values()).state_dict().keys())
+    assert ks[0] == "1.to_k_ip.weight" and len(ks) == 2 * sum(k.endswith("attn2.processor") for k in procs)
+    bad = {"conv_in.weight": torch.zeros(1)}
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(KeyError):
+        UNet2DConditionModel.from_safetensors(str(tmp_path / "bad.safetensors"), cfg)
