@@ -98,5 +98,33 @@ def main():
         print("resampler", name, tuple(y.shape))
 
 
+def unet_fixture():
+    """Reduced-width UNet forward + 2-step DDIM/CFG trajectory produced by the ORACLE itself (diffusers cannot be
+    executed here, so this pins the oracle against drift, not against the reference)."""
+    from .pipeline import denoise, install_ip_processors
+    from .schedulers import DDIMScheduler
+    from .sdxl_unet import UNet2DConditionModel, tiny_config
+    from . import modules as om
+    cfg = tiny_config()
+    u = det_fill(UNet2DConditionModel(cfg), 5).eval()
+    procs = install_ip_processors(u, num_tokens=4, scale=0.8)
+    for n, p in procs.items():
+        if isinstance(p, om.IPAttnProcessor2_0):
+            det_fill(p, 7, prefix=n)
+    x, ehs = det_randn((2, 4, 32, 32), 3), det_randn((2, 81, cfg.cross_attention_dim), 4)
+    te = det_randn((2, cfg.pooled_dim), 6)
+    ids = torch.tensor([[256, 256, 0, 0, 256, 256]], dtype=torch.float32).repeat(2, 1)
+    fwd = u(x, torch.tensor(500.0), ehs, added_cond_kwargs={"text_embeds": te, "time_ids": ids})[0]
+    lat = det_randn((1, 4, 32, 32), 3)
+    pe, ne = det_randn((1, 81, cfg.cross_attention_dim), 4), det_randn((1, 81, cfg.cross_attention_dim), 5)
+    po, no = det_randn((1, cfg.pooled_dim), 6), det_randn((1, cfg.pooled_dim), 7)
+    traj = []
+    denoise(u, DDIMScheduler(), lat, pe, ne, po, no, 256, 256, num_inference_steps=2, guidance_scale=5.0, trace=traj)
+    return {"forward": fwd.half(), "ddim_step1": traj[0].half(), "ddim_step2": traj[1].half()}
+
+
 if __name__ == "__main__":
     main()
+    with torch.no_grad():
+        torch.save(unet_fixture(), os.path.join(OUT, "oracle_tiny_unet.pt"))
+    print("oracle_tiny_unet.pt written")

@@ -92,3 +92,17 @@ def test_tiny_unet_denoise_runs_and_scale_gating():
                     control_guidance_end=0.0)       # IP scale gated off on every step
         assert a.shape == lat.shape and torch.isfinite(a).all()
         assert (a - b).abs().max() > 1e-4           # the IP branch matters
+
+
+def test_oracle_unet_matches_its_committed_fixture():
+    """tests/golden/oracle_tiny_unet.pt was produced by the oracle itself (oracle/gen_golden.py: diffusers cannot be
+    executed here, so this guards the restatement against drift; it is not a reference pin)."""
+    import os
+    from conftest import GOLDEN
+    from oracle.gen_golden import unet_fixture
+    g = torch.load(os.path.join(GOLDEN, "oracle_tiny_unet.pt"))
+    with torch.no_grad():
+        now = unet_fixture()
+    for k in g:
+        a, b = now[k].float(), g[k].float()
+        assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) < 2e-3, k
