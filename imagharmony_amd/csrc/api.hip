@@ -84,7 +84,7 @@ static int do_attn(const imh_attn_args* a, hipStream_t s) {
     p.Q = a->Q; p.K = a->K; p.Vt = a->Vt; p.K2 = a->K2; p.Vt2 = a->Vt2; p.O = a->O;
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.Lk_pad = a->Lk_pad; p.Lk2 = a->Lk2; p.Lk2_pad = a->Lk2_pad;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldk2 = a->ldk2; p.ldvt2 = a->ldvt2; p.ldo = a->ldo;
-    p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step; p.ablate = 0;
+    p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return attention_launch(p, a->dtype, s);
 }
@@ -187,7 +187,6 @@ extern "C" {
 int imh_abi_version(void) { return IMH_ABI_VERSION; }
 int imh_debug_set(int key, int value) {
     if (key == 0) { g_attn_force_nw = value; return IMH_OK; }
-    if (key == 1) { g_attn_ablate = value; return IMH_OK; }
     if (key == 2) { g_xcd_mode = value; return IMH_OK; }
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;

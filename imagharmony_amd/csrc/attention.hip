@@ -21,7 +21,6 @@
 namespace imh {
 
 int g_attn_force_nw = 0;   // debugging / tuning override (imh_debug_set)
-int g_attn_ablate = 0;     // ablation bits (imh_debug_set key 1): 1 no QK^T, 2 no softmax, 4 no PV, 8 no loads in loop
 
 constexpr int ATT_KV = 64;              // keys per LDS tile
 constexpr int ATT_TILE_BYTES = 64 * 128;

@@ -50,14 +50,12 @@ struct AttnParams {
     float scale2;     // weight of the second attention (IP scale)
     const float* scale2_tab;  // optional per-step table of IP scales, indexed by *step
     const int* step;
-    int ablate;               // tuning only
     const void* pf_ptr;       // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
 extern int g_xcd_mode;
-extern int g_attn_ablate;
 
 struct SmallAttnParams {
     const void* Q; const void* K; const void* V; void* O;

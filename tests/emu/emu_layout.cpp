@@ -148,15 +148,10 @@ static int test_attention(int Lk_valid, int Lk_pad) {
                     const int key = kbase + kt * 32 + st_key(r, hi);
                     float s = st[kt][lane][r] * c; s = key < Lk_valid ? s : -1e30f; st[kt][lane][r] = s; mx = std::max(mx, s);
                 }
-                m_run[lane] = mx;   // per-lane partial; combined below
+                m_run[lane] = mx;   // per-lane partial maximum of this tile; combined across halves below
             }
-            for (int lane = 0; lane < 64; ++lane) {
-                const float mx = std::max(m_run[lane], m_run[lane ^ 32]);   // __shfl_xor(…, 32) on this tile's max
-                (void)mx;
-            }
-            // emulate exactly: tile max across halves, then running max kept in a separate array
-            static float run_m[4][64]; static bool init[4] = {false, false, false, false};
-            if (t == 0) { for (int l = 0; l < 64; ++l) run_m[wave][l] = -1e30f; init[wave] = true; }
+            static float run_m[4][64];
+            if (t == 0) for (int l = 0; l < 64; ++l) run_m[wave][l] = -1e30f;
             float tile_m[64];
             for (int lane = 0; lane < 64; ++lane) tile_m[lane] = std::max(m_run[lane], m_run[lane ^ 32]);
             for (int lane = 0; lane < 64; ++lane) {
