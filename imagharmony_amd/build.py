@@ -1,32 +1,53 @@
-"""In-tree build of libimh_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+"""In-tree build of libimh_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+Sources are compiled to objects in parallel, then linked; objects live under csrc/_obj (git-ignored)."""
 import glob
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "libimh_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "imh.h")]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "imh.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
 def build(force=False, verbose=True):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + sources()
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [hipcc] + CFLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -420,17 +420,13 @@ static int launch_ring(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm_ring_kernel");
 }
 
-// variant codes (bm field of the config): 256 -> 256x{128,256}; 1128 -> 128x128 4-stage, 1 block/CU
+// variant codes (bm field of the config): 256 -> ring 256x{128,256}; 3128 / 3064 -> KG2 128x128 / 64x64.
+// (128x128 rings with 3-4 stages at one workgroup per CU and 256x128 with 2 stages were measured and dropped.)
 template <typename T, bool CONV>
 static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
     if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
-    if (bm == 1128 && bn == 128) return launch_ring<T, 128, 128, 2, 2, 4, CONV>(p, stream);
-    if (bm == 2128 && bn == 128) return launch_ring<T, 128, 128, 2, 2, 3, CONV>(p, stream);
-    if (bm == 1256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 2, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);
-    if (bm == 3128 && bn == 64) return launch_kg2<T, 128, 64, CONV>(p, stream);
-    if (bm == 3064 && bn == 128) return launch_kg2<T, 64, 128, CONV>(p, stream);
     if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
     set_error("gemm_ring: unsupported variant %dx%d", bm, bn);
     return IMH_ERR_ARG;

@@ -59,7 +59,7 @@ def graph_time(emit, dtype, n=20, reps=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="128,128,1;64,128,1;256,128,1;256,256,1;1128,128,1;2128,128,1;1256,128,1;256,128,2;256,256,2")
+    ap.add_argument("--variants", default="128,128,1;64,128,1;64,64,1;256,128,1;256,256,1;3128,128,1;3064,64,1")
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]

@@ -4,7 +4,7 @@ from imagharmony_amd.ctx import Ctx
 from tools.gemm_bench import timeit
 DEV="cuda:0"; dtype=torch.bfloat16
 ctx=Ctx(DEV,dtype)
-variants=[(128,128,1),(256,128,1),(1256,128,1),(256,256,1),(1128,128,1)]
+variants=[(128,128,1),(256,128,1),(256,256,1),(3128,128,1)]
 for (M,N,K) in [(8192,5120,2560),(8192,8192,8192),(4096,4096,4096),(2048,10240,1280),(8192,5120,640)]:
     x=torch.randn(M,K,device=DEV).to(dtype); w=(torch.randn(N,K,device=DEV)*K**-0.5).to(dtype); out=torch.empty(M,N,device=DEV,dtype=dtype)
     line=f"M={M} N={N} K={K}:"
