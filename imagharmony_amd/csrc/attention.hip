@@ -38,7 +38,9 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
     constexpr int RND = 8 / NW;              // staging rounds: NW*8 rows per round, 64 rows per tile
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES];
+    // K / V^T ring, then a wave-private [32 NW][64] Q / O staging tile (coalesced 128-B rows both ways)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES + 32 * NW * 128];
+    unsigned char* qs = smem + ATT_STAGES * 2 * ATT_TILE_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,15 +57,25 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
     if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
     const int hb = item / gx, qblk = item - hb * gx;
     const int b = hb / p.H, h = hb - b * p.H;
-    const int q = qblk * (32 * NW) + wave * 32 + l32;
-    const int qc = min(q, p.Lq - 1);
+    const int q0 = qblk * (32 * NW);
+    const int q = q0 + wave * 32 + l32;
 
-    // Q^T B-operand: lane (col q, half hi) holds d = sd*16 + hi*8 + 0..7
+    // Q tile through LDS: each wave DMA-copies its own 32 rows as full 128-B lines (a lane-per-row register load
+    // touches 32 different lines per instruction), then reads the Q^T B-operand fragments
+    // (lane (col q, half hi) holds d = sd*16 + hi*8 + 0..7) with the K-tile swizzle.
     v8 qf[4];
     {
-        const T* qp = (const T*)p.Q + ((size_t)b * p.Lq + qc) * p.ldq + h * 64 + hi * 8;
 #pragma unroll
-        for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qp + sd * 16);
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            const int ch = stage_chunk_x(row, lane);
+            const T* src = (const T*)p.Q + ((size_t)b * p.Lq + min(q0 + row, p.Lq - 1)) * p.ldq + h * 64 + ch * 8;
+            glds16(src, qs + (wave * 32 + i * 8) * 128);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own rows only: no workgroup barrier needed
+        const int row = wave * 32 + l32;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qs + tile_off(row, sd * 2 + hi, swz_x(row)));
     }
 
     const float c = p.scale * LOG2E;      // > 0
@@ -202,9 +214,12 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
             for (int r = 0; r < 16; ++r) fin[dt][r] += o[dt][r] * inv;
     }
 
-    // ---- store: lane (q, hi) owns d = dt*32 + 8*(r>>2) + 4*hi + (r&3) ----
-    if (q < p.Lq) {
-        T* op = (T*)p.O + ((size_t)b * p.Lq + q) * p.ldo + h * 64 + 4 * hi;
+    // ---- store through the wave's staging rows: lane (q, hi) owns d = dt*32 + 8*rg + 4*hi + e, written as 8-B
+    //      pieces, read back as full 128-B rows (8 lanes x 16 B) and stored coalesced ----
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // Q fragment reads of this wave are done
+        const int row = wave * 32 + l32;
+        const int sw = swz_x(row);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -212,8 +227,17 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
                 v4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(fin[dt][rg * 4 + e]);
-                *(v4*)(op + dt * 32 + rg * 8) = o4;
+                *(v4*)(qs + tile_off(row, dt * 4 + rg, sw) + hi * 8) = o4;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // same-wave LDS hand-off (DS ops retire in order)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r2 = wave * 32 + i * 8 + (lane >> 3);
+            const int ch = lane & 7;
+            const v8 o8 = *(const v8*)(qs + tile_off(r2, ch, swz_x(r2)));
+            if (q0 + r2 < p.Lq)
+                *(v8*)((T*)p.O + ((size_t)b * p.Lq + q0 + r2) * p.ldo + h * 64 + ch * 8) = o8;
+        }
     }
     tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
 }
@@ -286,7 +310,7 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
         set_error("attention: Lk2=%d Lk2_pad=%d invalid", p.Lk2, p.Lk2_pad);
         return IMH_ERR_SHAPE;
     }
-    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 3) || (p.K2 && ((p.ldk2 & 7) || (p.ldvt2 & 7)))) {
+    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 7) || (p.K2 && ((p.ldk2 & 7) || (p.ldvt2 & 7)))) {
         set_error("attention: leading dimensions must be multiples of 8 elements");
         return IMH_ERR_SHAPE;
     }
