@@ -116,8 +116,8 @@ class AttnProcessor2_0(nn.Module):
         super().__init__()
 
     # -- recorded / fused path ------------------------------------------------------------
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None):
-        """x: [B*L, C].  Returns to_out(attention(x)) (+ residual).
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None, rowstats=False):
+        """x: [B*L, C].  Returns to_out(attention(x)) (+ residual)  [, row-statistics partials if rowstats].
         ln = (norm module, stats [M,2]): x is the UN-normalised residual stream and LayerNorm is folded into the
         projections; otherwise x is already layer-normed.
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
@@ -140,7 +140,7 @@ class AttnProcessor2_0(nn.Module):
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="self.to_out")
+                       descr="self.to_out", rowstats=rowstats)
         ctx.free(qk); ctx.free(vt); ctx.free(ao)
         return out
 
@@ -191,7 +191,7 @@ class IPAttnProcessor2_0(nn.Module):
             kv.k2, kv.vt2, kv.lk2, kv.lk2_pad = project_kv(ctx, ip, _w(self.to_k_ip, ctx), _w(self.to_v_ip, ctx))
         return kv
 
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None):
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None, rowstats=False):
         C_ = x.shape[1]
         H = attn.heads
         if ln is None:
@@ -211,7 +211,7 @@ class IPAttnProcessor2_0(nn.Module):
             ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
                           descr="cross.attn")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="cross.to_out")
+                       descr="cross.to_out", rowstats=rowstats)
         ctx.free(q); ctx.free(ao)
         return out
 

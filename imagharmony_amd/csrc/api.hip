@@ -33,7 +33,7 @@ int check_launch(const char* what) {
 static GemmParams to_gemm(const imh_gemm_args* a) {
     GemmParams p;
     p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
-    p.residual = a->residual; p.ln_stat = a->ln_stat; p.ln_s = a->ln_s; p.ln_c = a->ln_c;
+    p.residual = a->residual; p.ln_stat = a->ln_stat; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.stats_out = a->stats_out;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
@@ -152,7 +152,7 @@ static int run_op(const imh_op& o, hipStream_t s) {
             return layernorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
         }
         case IMH_OP_LN_STATS: {
-            if (!o.u.norm.x || !o.u.norm.y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
+            if ((!o.u.norm.x && !o.u.norm.partial) || !o.u.norm.y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
             return layernorm_stats_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
         }
         case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
@@ -217,7 +217,7 @@ int imh_layernorm(const imh_norm_args* a, void* stream) {
 }
 
 int imh_layernorm_stats(const imh_norm_args* a, void* stream) {
-    if (!a || !a->x || !a->y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
+    if (!a || (!a->x && !a->partial) || !a->y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
     return layernorm_stats_launch(to_norm(a), a->dtype, (hipStream_t)stream);
 }
 

@@ -24,9 +24,30 @@ int g_attn_force_nw = 0;   // debugging / tuning override (imh_debug_set)
 
 constexpr int ATT_KV = 64;              // keys per LDS tile
 constexpr int ATT_TILE_BYTES = 64 * 128;
-constexpr int ATT_STAGES = 2;             // K/V^T ring depth (2 measured best in situ: 3.33 ms/forward vs 3.42 at 4 and 3.92 at 3)
+constexpr int ATT_STAGES = 3;             // K/V^T ring depth: 48 KB -> 3 workgroups per CU (the Q / O staging tile aliases the ring)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// three-input max in one VALU op; fmaxf() would add a canonicalising v_max(x, x) per MFMA-produced operand
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max over the two half-waves (lanes l and l^32) without LDS: v_permlane32_swap leaves {lo,lo} / {hi,hi}
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+// ATT_ABL (tools/attn_ablate.py only; wrong results by design), bit mask: 1 = no v_exp, 2 = no K/V loads inside the
+// loop, 4 = no barrier (with 2), 8 = no max / exponent / sum at all,
+// 16 = never wait for the K/V loads, 32 = always load tile 0 (cache-hot)
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
+#define ATT_EXP2(x) ((ATT_ABL & 9) ? (x) : __builtin_amdgcn_exp2f(x))
 
 // NW waves per workgroup (32 queries each).  The grid is (ceil(Lq / (32 NW)), H, B): NW is picked by the
 // launcher so that the number of workgroups is a multiple of what the chip holds at once (SDXL: L=4096 ->
@@ -39,8 +60,9 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     // K / V^T ring, then a wave-private [32 NW][64] Q / O staging tile (coalesced 128-B rows both ways)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES + 32 * NW * 128];
-    unsigned char* qs = smem + ATT_STAGES * 2 * ATT_TILE_BYTES;
+    static_assert(32 * NW * 128 <= ATT_STAGES * 2 * ATT_TILE_BYTES, "Q/O staging must fit inside the ring");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES];
+    unsigned char* qs = smem;              // used before the first K/V tile is staged and after the last is consumed
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,6 +98,8 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
         const int row = wave * 32 + l32;
 #pragma unroll
         for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qs + tile_off(row, sd * 2 + hi, swz_x(row)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave has its Q fragments: the ring may overwrite the staging rows
     }
 
     const float c = p.scale * LOG2E;      // > 0
@@ -127,36 +151,53 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
             if (s < ntiles) stage(s, s);
         int cur = 0;
         for (int t = 0; t < ntiles; ++t) {
-            if (t + ATT_STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ATT_STAGES - 2) * LPT) : "memory");
+            if (ATT_ABL & 16) {
+            } else if (t + ATT_STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ATT_STAGES - 2) * LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // tile t landed for every wave; tile t-1 fully consumed
+            if (!(ATT_ABL & 4)) __builtin_amdgcn_s_barrier();      // tile t landed for every wave; tile t-1 fully consumed
             asm volatile("" ::: "memory");
-            if (t + ATT_STAGES - 1 < ntiles) {
+            if (!(ATT_ABL & 2) && t + ATT_STAGES - 1 < ntiles) {
                 int ns = cur + ATT_STAGES - 1;
                 if (ns >= ATT_STAGES) ns -= ATT_STAGES;
-                stage(ns, t + ATT_STAGES - 1);
+                stage(ns, (ATT_ABL & 32) ? 0 : t + ATT_STAGES - 1);
             }
             const unsigned char* ks = smem + cur * 2 * ATT_TILE_BYTES;
             const unsigned char* vs = ks + ATT_TILE_BYTES;
             const int kbase = t * ATT_KV;
-            const bool second = kbase + 32 < Lk;   // wave-uniform: is the 2nd 32-key sub-tile live?
             const bool ragged = kbase + ATT_KV > Lk;   // only the last tile of a ragged key set needs masking
 
-            // ---- S^T = K Q^T ----
+            // ---- S^T = K Q^T (both 32-key sub-tiles always: padded keys are zero rows, masked below).
+            //      MFMA and VALU time add up on a SIMD (tools/attn_ablate.py), so LDS latency is what can be hidden:
+            //      all 8 K fragments are requested before the first MFMA, the 8 V^T fragments right after the
+            //      QK^T MFMAs so that they land under the softmax ----
             f32x16 st[2];
+            {
+                v8 kf[2][4];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-                if (kt == 1 && !second) continue;
+                    for (int sd = 0; sd < 4; ++sd) kf[kt][sd] = *(const v8*)(ks + att_k_off(lane, kt, sd));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int sd = 0; sd < 4; ++sd) {
-                    v8 kf = *(const v8*)(ks + att_k_off(lane, kt, sd));
-                    st[kt] = mfma32(kf, qf[sd], st[kt]);
+                for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+                    for (int sd = 0; sd < 4; ++sd) st[kt] = mfma32(kf[kt][sd], qf[sd], st[kt]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            v8 vf[2][2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) vf[kt][s][dt] = *(const v8*)(vs + att_v_off(lane, dt, kt, s));
+            __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax on RAW scores (scale folded into the exponent: p = exp2(s*c - m*c), c > 0);
-            //      the row is lane-local, one cross-half exchange per tile ----
+            //      the row is lane-local, one cross-half exchange per tile; written for v_max3 / v_pk_fma /
+            //      v_pk_add (half the VALU instructions of the scalar form) ----
             if (ragged) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -164,21 +205,29 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
                     for (int r = 0; r < 16; ++r)
                         if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
             }
-            float mx = fmaxf(st[0][0], st[1][0]);
+            float mx = max3f(st[0][0], st[1][0], st[0][1]);
+            if (!(ATT_ABL & 8)) {
+                mx = max3f(mx, st[1][1], st[0][2]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
+                mx = fmaxf(mx, st[1][15]);
+                mx = xhalf_max(mx);
+            }
             const float m_new = fmaxf(m_run, mx);
-            const float mc = m_new * c;
-            float psum = 0.f;
+            const f32x2 c2 = {c, c};
+            const f32x2 nmc2 = {-m_new * c, -m_new * c};
+            f32x2 ps2 = {0.f, 0.f};
             v8 pf[2][2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c, -mc));
-                    psum += pv;
-                    pf[kt][r >> 3][r & 7] = from_f32<T>(pv);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 s2 = {st[kt][r], st[kt][r + 1]};
+                    const f32x2 e2 = (ATT_ABL & 8) ? s2 : __builtin_elementwise_fma(s2, c2, nmc2);
+                    const f32x2 p2 = {ATT_EXP2(e2[0]), ATT_EXP2(e2[1])};
+                    if (!(ATT_ABL & 8)) ps2 += p2;
+                    pf[kt][r >> 3][r & 7] = from_f32<T>(p2[0]);
+                    pf[kt][r >> 3][(r & 7) + 1] = from_f32<T>(p2[1]);
                 }
             if (__any(m_new != m_run)) {           // wave-uniform: rescale only when some row's max moved
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -189,19 +238,15 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
                 m_run = m_new;
             }
-            l_run += psum;
+            l_run += ps2[0] + ps2[1];
             // ---- O^T += V^T P^T ----
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                if (kt == 1 && !second) continue;
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        v8 vf = *(const v8*)(vs + att_v_off(lane, dt, kt, s));
-                        o[dt] = mfma32(vf, pf[kt][s], o[dt]);
-                    }
-            }
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s][dt], pf[kt][s], o[dt]);
             asm volatile("" ::: "memory");
             if (++cur == ATT_STAGES) cur = 0;
         }

@@ -11,6 +11,8 @@
 //   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
 // Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
 // indexed by *step instead of the immediate f0..f2 fields.
+#include <algorithm>
+
 #include "imh_common.h"
 #include "imh_kernels.h"
 
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const EwParams p) {
     extern __shared__ float wl[];   // [36][C0] transposed weights, then [C0] bias
     const int S = p.i0, H = p.i1, W = p.i2, C0 = p.i3, Bout = p.i4;
     const T* w = (const T*)p.w;
-    for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
-        const int co = i / 36, k = i % 36;
-        wl[k * C0 + co] = to_f32(w[i]);
+    for (int co = threadIdx.x; co < C0; co += blockDim.x) {      // one output channel (36 contiguous taps) per thread
+#pragma unroll
+        for (int k = 0; k < 36; ++k) wl[k * C0 + co] = to_f32(w[co * 36 + k]);
     }
     for (int i = threadIdx.x; i < C0; i += blockDim.x) wl[36 * C0 + i] = p.bias ? to_f32(((const T*)p.bias)[i]) : 0.f;
     __syncthreads();
@@ -190,7 +192,8 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
             if (p.i3 & 7) { set_error("conv_in: C0 must be a multiple of 8"); return IMH_ERR_SHAPE; }
             const size_t lds = (size_t)(37 * p.i3) * sizeof(float);
             const long long work = (long long)p.i4 * p.i1 * p.i2 * (p.i3 >> 3);
-            hipLaunchKernelGGL((conv_in_kernel<T>), dim3(grid_for(work, 256 * 4)), dim3(256), lds, stream, p);
+            // persistent workgroups (3 per CU by LDS): the 46 KB weight transpose is paid 768 times, not once per 1024 outputs
+            hipLaunchKernelGGL((conv_in_kernel<T>), dim3(std::min(grid_for(work, 256), 768)), dim3(256), lds, stream, p);
             break;
         }
         case EW_CFG_STEP:

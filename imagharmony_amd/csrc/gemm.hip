@@ -173,26 +173,61 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
 
     // ---- epilogue: lane owns columns nb .. nb+4*FN-1 of row m ----
     const int nb = n0 + out_col(lane, wn, BN);
+    const bool row_stats = p.stats_out != nullptr;     // workgroup-uniform
+    // folded-LayerNorm operands of this lane's columns: fetched once here (after the K loop, so they cost no
+    // registers inside it), not once per output row
+    float lnpre[8 * FN];
+    const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + out_row(lane, wm, BM, i);
-        if (m >= p.M || nb >= p.N) continue;
+        const bool active = m < p.M && nb < p.N;
+        if (!active && !row_stats) continue;
         float v[4 * FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
-        if (p.splits > 1) {
-            float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
-            if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+        if (active) {
+            if (p.splits > 1) {
+                float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+                if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
 #pragma unroll
-                for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+                    for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+                }
             } else {
-#pragma unroll
-                for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+                epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre);   // leaves the final (un-rounded) values in v
             }
-        } else {
-            epilogue_store<T, FN>(p, v, m, nb);
+        }
+        if (row_stats) {
+            // Row statistics of the stored tile for the next LayerNorm: one (sum, M2) partial per 32-column slot
+            // (M2 = squared deviations from the slot mean; combined exactly by ln_finalize_kernel, norm.hip).
+            // A slot is owned by LPS adjacent column-quads of one wave: 2 (FN = 4) or 4 (FN = 2) lanes 16 apart.
+            constexpr int LPS = 32 / (4 * FN);
+            static_assert(LPS == 2 || LPS == 4, "row statistics need 64- or 128-column tiles");
+            const int col0 = nb & ~31;
+            const int nval = min(32, p.N - col0);
+            float r[4 * FN];
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4 * FN; ++q) {
+                r[q] = (active && nb + q < p.N) ? to_f32(from_f32<T>(v[q])) : 0.f;
+                sum += r[q];
+            }
+            sum = xor16_sum(sum);
+            if (LPS == 4) sum = xor32_sum(sum);
+            const float mean = sum / (float)max(nval, 1);
+            float m2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4 * FN; ++q)
+                if (active && nb + q < p.N) { const float d = r[q] - mean; m2 += d * d; }
+            m2 = xor16_sum(m2);
+            if (LPS == 4) m2 = xor32_sum(m2);
+            if (((lane >> 4) & (LPS - 1)) == 0 && m < p.M && col0 < p.N)
+                *(float2*)(p.stats_out + 2 * ((size_t)(col0 >> 5) * p.M + m)) = make_float2(sum, m2);
         }
     }
     if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, gridDim.x, tid, 256);
@@ -350,6 +385,10 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
+    if (p.stats_out && (p.splits > 1 || bm >= 256 || (p.flags & (GF_GEGLU | GF_OUT_F32)))) {
+        set_error("gemm: stats_out needs a plain 64/128 tile, splits == 1, no GEGLU / fp32 output (bm=%d splits=%d flags=%d)", bm, p.splits, p.flags);
+        return IMH_ERR_ARG;
+    }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);
     if (dtype == IMH_DT_F16) return launch_typed<f16_t>(p, conv, bm, bn, stream);
     set_error("gemm: unknown dtype %d", dtype);

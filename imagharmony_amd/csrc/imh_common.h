@@ -88,6 +88,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// butterfly steps between lanes 16 / 32 apart on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap; no LDS
+// round trip like ds_bpermute): swapping x with itself leaves {r0,r0,r2,r2} / {r1,r1,r3,r3} (rows of 16 lanes),
+// resp. {lo,lo} / {hi,hi}, whose sum is the pair sum in every lane.
+__device__ __forceinline__ float xor16_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -17,6 +17,7 @@ struct GemmParams {
     const float* ln_stat;  // [rows, 2] (mean, rstd) of the un-normalised operand rows (row form: per m; col form: per n)
     const float* ln_s;     // sum_k gamma_k W[.,k]   (row form: per n; col form: per m)
     const float* ln_c;     // sum_k beta_k  W[.,k]   (same indexing as ln_s)
+    float* stats_out;      // optional [ceil(N/32)][M][2] (sum, M2) slot partials of the output rows (see imh.h)
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;

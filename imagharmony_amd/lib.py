@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimh_hip.so")
+LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
@@ -20,7 +20,7 @@ _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 
 class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
-                ("residual", _vp), ("ln_stat", _vp), ("ln_s", _vp), ("ln_c", _vp),
+                ("residual", _vp), ("ln_stat", _vp), ("ln_s", _vp), ("ln_c", _vp), ("stats_out", _vp),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
@@ -107,7 +107,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.imh_abi_version() != 1:
+    if lib.imh_abi_version() != 2:
         raise ImhError("libimh_hip.so ABI version mismatch")
     _lib = lib
     return lib

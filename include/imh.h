@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 1
+#define IMH_ABI_VERSION 2
 
 enum imh_status {
     IMH_OK = 0,
@@ -85,6 +85,12 @@ typedef struct imh_gemm_args {
     const float* ln_stat;
     const float* ln_s;
     const float* ln_c;
+    /* Optional row statistics of the OUTPUT (so that the next LayerNorm needs no pass over Y): fp32
+     * [ceil(N/32)][M][2] partials (sum, sum of squared deviations from the slot mean) of every 32-column slot of
+     * every output row, taken on the stored (rounded) values.  imh_layernorm_stats with x == NULL turns them into
+     * (mean, rstd).  Only for the plain 2x2-wave tiles (bm in {64,128}, bn in {64,128}), splits == 1, no
+     * GEGLU / fp32 output; deterministic (no atomics).  NULL = off. */
+    float* stats_out;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -182,7 +188,9 @@ typedef struct imh_norm_args {
 int imh_groupnorm(const imh_norm_args* a, void* stream);
 size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int imh_layernorm(const imh_norm_args* a, void* stream);
-/* row statistics only: y = fp32 [rows, 2] (mean, rstd); consumed by imh_gemm with IMH_GF_LN_ROW / _COL */
+/* row statistics only: y = fp32 [rows, 2] (mean, rstd); consumed by imh_gemm with IMH_GF_LN_ROW / _COL.
+ * x != NULL: one pass over x [rows, C].  x == NULL: finalise the producer GEMM's slot partials
+ * (imh_gemm_args.stats_out) given in `partial`, C = row length. */
 int imh_layernorm_stats(const imh_norm_args* a, void* stream);
 
 /* ---- small fused elementwise kernels (see csrc/elementwise.hip for the field meaning) ---- */

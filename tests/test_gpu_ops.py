@@ -339,3 +339,27 @@ def test_gemm_folded_layernorm(L, dtype):
     y2, yt2 = ctx.gemm_dual(dict(x=x, w=wg, flags=L.GF_LN_ROW, ln=(stat, s, c)),
                             dict(x=wg, w=x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(stat, s, c)))
     assert torch.equal(y2, y) and torch.equal(yt2, ctx.gemm(wg, x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(stat, s, c), cfg=(128, 128, 1)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(64, 64, 1), (128, 64, 1), (64, 128, 1), (128, 128, 1)])
+@pytest.mark.parametrize("M,N", [(192, 1280), (100, 200), (256, 640)])
+def test_gemm_output_row_statistics(L, dtype, cfg, M, N):
+    """The producer GEMM's epilogue writes 32-column slot partials of its OUTPUT rows; finalised they must equal the
+    (mean, rstd) of the stored tensor -- so the next LayerNorm never re-reads it.  Large row mean = cancellation case."""
+    ctx = ctx_for(dtype)
+    K = 128
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias = (rnd(N, dtype=dtype, seed=3) + 2.0).contiguous()
+    res = rnd(M, N, dtype=dtype, seed=4)
+    y, part = ctx.gemm(x, w, bias=bias, residual=res, cfg=cfg, rowstats=True)
+    assert torch.equal(y, ctx.gemm(x, w, bias=bias, residual=res, cfg=cfg))          # the output itself is unchanged
+    stat = ctx.layernorm_stats(y, 1e-5, partials=part)
+    yr = y.float()
+    assert torch.allclose(stat[:, 0], yr.mean(1), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(stat[:, 1], (yr.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    two_pass = ctx.layernorm_stats(y, 1e-5) if N % 8 == 0 else None
+    if two_pass is not None:
+        assert torch.allclose(stat, two_pass, rtol=1e-4, atol=2e-5)
+    with pytest.raises(L.ImhError, match="stats_out"):
+        ctx.gemm(x, w, flags=L.GF_OUT_F32, cfg=cfg, rowstats=True)

@@ -99,3 +99,20 @@ def test_unet_forward_batch_and_ip_token_variants(dtype, B, T):
            added_cond_kwargs={"text_embeds": te.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
     r = rel_rms(y.float().cpu(), ref)
     assert r < TOL[dtype], f"B={B} T={T}: rel-rms {r:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_forward_with_folded_layernorm(dtype, monkeypatch):
+    """the optional LayerNorm-free transformer blocks (row statistics from the producer GEMM's epilogue, finalise
+    kernel, normalisation folded into the consumer GEMMs) meet the same oracle tolerance as the default path"""
+    import imagharmony_amd.unet as hunet
+    monkeypatch.setattr(hunet, "FOLD_LAYERNORM", True)
+    ou, hu, ocfg = build_pair(dtype)
+    x, ehs, te, ids = inputs(ocfg)
+    with torch.no_grad():
+        ref = ou(x, torch.tensor(500.0), ehs, added_cond_kwargs={"text_embeds": te, "time_ids": ids})[0]
+    y = hu(x.to(DEV), torch.tensor(500.0), ehs.to(DEV, dtype),
+           added_cond_kwargs={"text_embeds": te.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
+    r = rel_rms(y.float().cpu(), ref)
+    print(f"unet tiny folded-LN {dtype}: rel-rms {r:.3e}")
+    assert r < TOL[dtype], f"rel-rms {r:.3e}"
