@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--ip-tokens", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=1024)
-    ap.add_argument("--in-flight", type=int, default=1, help="PNS candidates in flight per GPU (one HIP stream each, batch 1 "
-                    "each); 1 = BASELINE.json configs[1] exactly")
+    ap.add_argument("--in-flight", type=int, default=2, help="EXTRA measurement (never `value`): PNS candidates in flight per "
+                    "GPU, one HIP stream each, batch 1 each; 1 = skip")
+    ap.add_argument("--stacked", type=int, default=4, help="EXTRA measurement (never `value`): PNS candidates stacked into one "
+                    "UNet batch per GPU (BASELINE.json configs[4] runs 4 per GPU); 1 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
                     "single-GPU testing of the multi-rank control path)")
     return ap.parse_args()
@@ -168,6 +170,23 @@ def main():
         torch.cuda.synchronize(device)
         return k * n_steps / (time.perf_counter() - t0)
 
+    def run_stacked(S, n_steps, n_warm):
+        """S candidates of this rank stacked into one UNet batch (2S with CFG): pns.run_pns(batch=S)"""
+        e = eng.__class__(unet, device, dtype, True)
+        e.set_conditioning(pe.repeat(S, 1, 1), ne.repeat(S, 1, 1), po.repeat(S, 1), no.repeat(S, 1), a.res, a.res,
+                           guidance_scale=5.0)
+        e.set_schedule(pipe.scheduler, a.denoise_steps)
+        z = torch.cat([pns.seed_latents(2000 + j, lat_shape) for j in range(S)], 0).to(device)
+        for _ in range(n_warm):
+            e.denoise(z)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            o = e.denoise(z)
+        torch.cuda.synchronize(device)
+        dt_s = time.perf_counter() - t0
+        return S * n_steps / dt_s, bool(torch.isfinite(o).all().item())
+
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
@@ -238,6 +257,11 @@ def main():
             res["concurrent_candidates"] = {"in_flight": a.in_flight, "images_per_sec": run_concurrent(a.in_flight, 2, 1),
                                             "note": "independent batch-1 denoises on separate HIP streams sharing weights and "
                                                     "conditioning; same arithmetic per image as `value`"}
+        if world == 1 and a.stacked > 1:
+            # extra, NOT the headline: the rank's candidates as one UNet batch (PNS with N > n_gpus, configs[4])
+            ips, ok = run_stacked(a.stacked, 2, 1)
+            res["stacked_candidates"] = {"per_forward": a.stacked, "images_per_sec": ips, "outputs_finite": ok,
+                                         "note": f"UNet batch {2 * a.stacked} (CFG); same arithmetic per image as `value`"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_res, a.ip_tokens, a.denoise_steps)

@@ -77,7 +77,7 @@ __global__ void concat_kernel(const EwParams p) {
 
 // conv_in: a = latents fp32 NCHW [S, 4, H, W]; w = weights T [C0][4][3][3]; bias T [C0];
 // y = NHWC T [Bout, H, W, C0] with Bout = i4 (batch b reads latent b % S: CFG duplication).
-// i0 = S, i1 = H, i2 = W, i3 = C0, f0 = input scale.  One thread = one pixel x 8 channels.
+// i0 = S, i1 = H, i2 = W, i3 = C0, f0 = input scale.  Eight threads per pixel, each 8 channels at a time.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in_kernel(const EwParams p) {
     typedef typename Vec<T>::v8 v8;
@@ -92,18 +92,18 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const EwParams p) {
     __syncthreads();
     const int cg = C0 >> 3;
     const float in_scale = p.tab ? p.tab[*p.step] : p.f0;
-    const long long total = (long long)Bout * H * W * cg;
+    // 8 threads per pixel: each fetches the pixel's 36 taps once (all loads in flight together; the 8 copies hit
+    // L1), then produces the channel octets l8, l8+8, .. -- the 8 threads of a pixel store 128 contiguous bytes
+    const long long total = (long long)Bout * H * W * 8;
     const float* lat = (const float*)p.a;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % cg);
-        const long long pix = i / cg;
+        const int l8 = (int)(i & 7);
+        const long long pix = i >> 3;
         const int x = (int)(pix % W);
         const int y = (int)((pix / W) % H);
         const int b = (int)(pix / ((long long)W * H));
         const float* src = lat + (size_t)(b % S) * 4 * H * W;
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = wl[36 * C0 + c8 * 8 + e];
+        float tap[36];
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -111,24 +111,29 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const EwParams p) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int iy = y + ky - 1, ix = x + kx - 1;
-                    float v = 0.f;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = src[((size_t)ci * H + iy) * W + ix] * in_scale;
+                    const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    const float v = in ? src[((size_t)ci * H + iy) * W + ix] * in_scale : 0.f;
                     // the model sees the latent rounded to the compute dtype (pipeline casts latents)
-                    v = to_f32(from_f32<T>(v));
-                    const float* wr = wl + (ci * 9 + ky * 3 + kx) * C0 + c8 * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
+                    tap[ci * 9 + ky * 3 + kx] = to_f32(from_f32<T>(v));
                 }
-        v8 o;
+        for (int c8 = l8; c8 < cg; c8 += 8) {
+            float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
-        ((v8*)p.y)[i] = o;
+            for (int e = 0; e < 8; ++e) acc[e] = wl[36 * C0 + c8 * 8 + e];
+#pragma unroll
+            for (int k = 0; k < 36; ++k) {
+                const float* wr = wl + k * C0 + c8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += tap[k] * wr[e];
+            }
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
+            ((v8*)p.y)[pix * cg + c8] = o;
+        }
     }
 }
 
-// a = noise prediction NHWC T [2S or S, HW, 4] (i3 = 1: CFG, batch order [uncond | cond]);
-// y = latents fp32 NCHW [S, 4, HW] updated in place: x' = f0*x + f1*eps, eps = u + f2*(c-u).
-// i0 = S, i1 = HW.  b (optional) = fp32 copy of eps out (NCHW), for tests.
 template <typename T>
 __global__ void cfg_step_kernel(const EwParams p) {
     const int S = p.i0, HW = p.i1;
@@ -191,7 +196,7 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
         case EW_CONV_IN: {
             if (p.i3 & 7) { set_error("conv_in: C0 must be a multiple of 8"); return IMH_ERR_SHAPE; }
             const size_t lds = (size_t)(37 * p.i3) * sizeof(float);
-            const long long work = (long long)p.i4 * p.i1 * p.i2 * (p.i3 >> 3);
+            const long long work = (long long)p.i4 * p.i1 * p.i2 * 8;
             // persistent workgroups (3 per CU by LDS): the 46 KB weight transpose is paid 768 times, not once per 1024 outputs
             hipLaunchKernelGGL((conv_in_kernel<T>), dim3(std::min(grid_for(work, 256), 768)), dim3(256), lds, stream, p);
             break;

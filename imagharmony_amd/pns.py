@@ -54,9 +54,12 @@ def broadcast_tensors_(tensors: Sequence[torch.Tensor], src: int = 0):
 
 def run_pns(denoise_fn: Callable[[torch.Tensor], torch.Tensor], seeds: Sequence[int], latent_shape,
             scorer: Callable[[torch.Tensor], torch.Tensor] = default_scorer, device="cpu",
-            final_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
-    """Each rank runs ``denoise_fn(noise [1,4,h,w]) -> latents`` for its share of ``seeds`` (the preview, or the
-    full denoise when ``final_fn`` is None), scores them, and the group agrees on the winner.
+            final_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, batch: int = 1):
+    """Each rank runs ``denoise_fn(noise [S,4,h,w]) -> latents [S,4,h,w]`` for its share of ``seeds`` (the preview,
+    or the full denoise when ``final_fn`` is None), scores them, and the group agrees on the winner.
+    ``batch`` = candidates per denoise call (S <= batch): with N > world seeds a rank stacks its candidates into one
+    UNet batch (BASELINE.json configs[4]: 4 per GPU -> UNet batch 8), 1.2-1.3x the images/sec of one at a time on
+    MI355X; candidates stay independent, so the scores do not depend on ``batch``.
 
     Returns dict(best_seed, best_score, scores [N], latents = the winner's latents on every rank;
     with ``final_fn`` the winner's noise is re-denoised by its owner rank and that result is returned)."""
@@ -67,10 +70,13 @@ def run_pns(denoise_fn: Callable[[torch.Tensor], torch.Tensor], seeds: Sequence[
     per = (len(seeds) + world - 1) // world
     local_scores = torch.full((per,), float("-inf"), dtype=torch.float32, device=device)
     local_lat = {}
-    for j, s in enumerate(mine):
-        lat = denoise_fn(seed_latents(s, latent_shape))
-        local_scores[j] = scorer(lat)[0].to(device)
-        local_lat[s] = lat.detach().clone()
+    for j0 in range(0, len(mine), max(1, int(batch))):
+        group = mine[j0:j0 + max(1, int(batch))]
+        lat = denoise_fn(torch.cat([seed_latents(s, latent_shape) for s in group], 0))
+        sc = scorer(lat)
+        for k, s in enumerate(group):
+            local_scores[j0 + k] = sc[k].to(device)
+            local_lat[s] = lat[k:k + 1].detach().clone()
     if world > 1:
         gathered = [torch.empty_like(local_scores) for _ in range(world)]
         dist.all_gather(gathered, local_scores)

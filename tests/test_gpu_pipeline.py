@@ -122,6 +122,36 @@ def test_pns_single_rank_on_device():
     assert torch.equal(direct, r1["latents"])
 
 
+def test_pns_candidates_batched_per_forward():
+    """configs[4]-style PNS: several candidate seeds of one rank stacked into one UNet batch (S=3 -> UNet batch 6).
+    Candidates are independent rows of every op, so each one matches its own batch-1 denoise to rounding and the
+    selection is unchanged."""
+    from imagharmony_amd import pns
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    pipe = StableDiffusionXLCustomPipeline(hu, scheduler=hs.DDIMScheduler(), device=DEV, dtype=dtype)
+    cd = ocfg.cross_attention_dim
+    pe, ne = det_randn((1, 81, cd), 4), det_randn((1, 81, cd), 5)
+    po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
+    seeds = [3, 9, 27]
+
+    def engine_for(S):
+        eng = pipe.engine if S == 1 else pipe.engine.__class__(hu, DEV, dtype, True)
+        eng.set_conditioning(pe.repeat(S, 1, 1), ne.repeat(S, 1, 1), po.repeat(S, 1), no.repeat(S, 1), 256, 256,
+                             guidance_scale=5.0)
+        eng.set_schedule(pipe.scheduler, 2)
+        return eng
+
+    e1, e3 = engine_for(1), engine_for(3)
+    one = pns.run_pns(lambda z: e1.denoise(z).clone(), seeds, (1, 4, 32, 32), device=DEV)
+    stacked = pns.run_pns(lambda z: e3.denoise(z).clone(), seeds, (1, 4, 32, 32), device=DEV, batch=3)
+    assert stacked["best_seed"] == one["best_seed"]
+    assert torch.allclose(stacked["scores"], one["scores"], atol=2e-2)
+    assert rel_rms(stacked["latents"].cpu(), one["latents"].cpu()) < 2e-2
+
+
 def test_hip_denoise_matches_committed_oracle_fixture():
     """the HIP engine against tests/golden/oracle_tiny_unet.pt (a committed oracle trajectory: the GPU box has no
     /root/reference and this also pins HIP vs oracle without recomputing the oracle)"""

@@ -12,10 +12,10 @@ from imagharmony_amd import pns
 
 
 def _fake_denoise(noise):
-    return noise * 0.5 + noise.mean()
+    return noise * 0.5 + noise.mean(dim=(1, 2, 3), keepdim=True)      # per candidate: batching must not mix them
 
 
-def _worker(rank, world, port, seeds, q):
+def _worker(rank, world, port, seeds, q, batch=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,7 +24,7 @@ def _worker(rank, world, port, seeds, q):
         with torch.no_grad():
             lin.weight.fill_(float(rank + 1))
         pns.broadcast_module_(lin, src=0)
-        r = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0)
+        r = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0, batch=batch)
         q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].sum().item(), lin.weight[0, 0].item(), r["owner"]))
     finally:
         dist.destroy_process_group()
@@ -38,13 +38,20 @@ def _free_port():
     return p
 
 
-def test_pns_world2_matches_single_process():
-    seeds = [11, 7, 3, 19, 5]
+import pytest
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_pns_world2_matches_single_process(batch):
+    """batch = candidates stacked per denoise call on a rank (configs[4]: 4 per GPU): same scores, same winner"""
+    seeds = [11, 7, 3, 19, 5, 23, 2]
     single = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0)
+    batched = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0, batch=3)
+    assert batched["best_seed"] == single["best_seed"] and torch.equal(batched["scores"], single["scores"])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, seeds, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, seeds, q, batch)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
