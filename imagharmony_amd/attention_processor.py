@@ -177,6 +177,7 @@ class IPAttnProcessor2_0(nn.Module):
         self.scale = scale
         self.num_tokens = num_tokens
         self.skip = skip
+        self.store_attn_map = False     # True: keep the reference's `attn_map` side output (eager __call__ only)
         self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
 
@@ -229,10 +230,43 @@ class IPAttnProcessor2_0(nn.Module):
         out = self.emit(ctx, attn, x, B, L_, residual=res, kv=kv).view(B, L_, C_)
         if attn.rescale_output_factor != 1.0:
             out = out / attn.rescale_output_factor
+        if getattr(self, "store_attn_map", False) and not self.skip:
+            # Visualisation hook of the reference (attention_processor.py:443-444, read and deleted by
+            # utils.py:9-11): q @ softmax(k_ip^T) -- upstream's operator precedence puts the softmax on k_ip^T.
+            # Off by default (an extra [B, H, L, T] tensor per layer per step); plain device matmuls, not on
+            # the fused / graph path.
+            H = attn.heads
+            ip = encoder_hidden_states[:, encoder_hidden_states.shape[1] - self.num_tokens:]
+            q = torch.nn.functional.linear(hidden_states, attn.to_q.weight.to(hidden_states.dtype))
+            ik = torch.nn.functional.linear(ip, self.to_k_ip.weight.to(hidden_states.dtype))
+            qh = q.view(B, L_, H, C_ // H).transpose(1, 2)
+            ikh = ik.view(B, -1, H, C_ // H).transpose(1, 2)
+            self.attn_map = qh @ ikh.transpose(-2, -1).softmax(dim=-1)
         return out
+
+
+class CNAttnProcessor2_0:
+    """ControlNet processor (reference: attention_processor.py:534-621; installed by ip_adapter.py:127-133 on every
+    attention layer of a ControlNet): self-attention unchanged, cross-attention on the text tokens only -- the last
+    ``num_tokens`` (image-prompt) tokens are sliced off.  No parameters, like upstream."""
+
+    def __init__(self, num_tokens=4):
+        self.num_tokens = num_tokens
+        self.skip = True            # prepare_kv / emit below read these three like an IPAttnProcessor2_0(skip=True)
+        self.scale = 0.0
+
+    prepare_kv = IPAttnProcessor2_0.prepare_kv
+    emit = IPAttnProcessor2_0.emit
+
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, *args, **kwargs):
+        if encoder_hidden_states is None:
+            return AttnProcessor2_0()(attn, hidden_states, None, attention_mask, temb)
+        return IPAttnProcessor2_0.__call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb)
 
 
 # the reference aliases these names when torch >= 2 (ip_adapter/ip_adapter.py:13-24); the isinstance()
 # checks in set_scale (ip_adapter.py:181, custom_pipelines.py:19,320) go through them
 AttnProcessor = AttnProcessor2_0
 IPAttnProcessor = IPAttnProcessor2_0
+CNAttnProcessor = CNAttnProcessor2_0

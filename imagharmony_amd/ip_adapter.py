@@ -6,7 +6,7 @@ under ``down_blocks.2.attentions.1`` (:117; the ``target_blocks`` argument is ig
 """
 import torch
 
-from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+from .attention_processor import AttnProcessor2_0, CNAttnProcessor2_0, IPAttnProcessor2_0
 
 ACTIVE_BLOCK = "down_blocks.2.attentions.1"
 
@@ -50,7 +50,7 @@ def set_scale(unet, scale):
 import os
 from typing import List
 
-from .modules import HarmonyAttention, ImageProjModel, Resampler  # noqa: E402,F401
+from .modules import HarmonyAttention, ImageProjModel, MLPProjModel, Resampler  # noqa: E402,F401
 from .utils import get_generator  # noqa: E402
 
 IPAttnProcessor = IPAttnProcessor2_0
@@ -92,8 +92,12 @@ class IPAdapter:
                               clip_embeddings_dim=self.clip_embeddings_dim,
                               clip_extra_context_tokens=self.num_tokens).to(self.device, dtype=self.dtype)
 
-    def set_ip_adapter(self):                                             # ip_adapter.py:99-125
+    def set_ip_adapter(self):                                             # ip_adapter.py:99-133
         install_ip_processors(self.pipe.unet, num_tokens=self.num_tokens, device=self.device, dtype=self.dtype)
+        cn = getattr(self.pipe, "controlnet", None)                       # :126-133: text-only cross-attention there
+        if cn is not None:
+            for c in (getattr(cn, "nets", None) or [cn]):
+                c.set_attn_processor(CNAttnProcessor2_0(num_tokens=self.num_tokens))
 
     def load_ip_adapter(self, state_dict=None):                           # ip_adapter.py:135-154
         if state_dict is None:
@@ -135,6 +139,37 @@ class IPAdapter:
 
     def set_scale(self, scale):                                           # ip_adapter.py:179-182
         set_scale(self.pipe.unet, scale)
+
+    def generate(self, pil_image=None, clip_image_embeds=None, prompt=None, negative_prompt=None, scale=1.0,
+                 num_samples=4, seed=None, guidance_scale=7.5, num_inference_steps=30, prompt_embeds=None, **kwargs):
+        """Base (SD-1.x style) generate, ip_adapter.py:184-247: the pipe's ``encode_prompt`` returns (cond, uncond)
+        and the pipe takes no pooled embeddings.  ``prompt_embeds`` = that 2-tuple when no text encoder is attached."""
+        self.set_scale(scale)
+        if pil_image is not None:
+            n = len(pil_image) if isinstance(pil_image, (list, tuple)) else 1
+        else:
+            n = clip_image_embeds.size(0)
+        prompt = prompt if prompt is not None else "best quality, high quality"
+        negative_prompt = negative_prompt if negative_prompt is not None else \
+            "monochrome, lowres, bad anatomy, worst quality, low quality"
+        if not isinstance(prompt, List):
+            prompt = [prompt] * n
+        if not isinstance(negative_prompt, List):
+            negative_prompt = [negative_prompt] * n
+        extra = {k: kwargs.pop(k) for k in ("uncond_clip_image_embeds",) if k in kwargs}   # IPAdapterPlus / Full, no CLIP attached
+        ipe, uipe = self.get_image_embeds(pil_image=pil_image, clip_image_embeds=clip_image_embeds, **extra)
+        bs, seq_len, _ = ipe.shape
+        tile = lambda t: t.repeat(1, num_samples, 1).view(bs * num_samples, seq_len, -1)        # :216-220
+        ipe, uipe = tile(ipe), tile(uipe)
+        if prompt_embeds is None:
+            prompt_embeds = self.pipe.encode_prompt(prompt, device=self.device, num_images_per_prompt=num_samples,
+                                                    do_classifier_free_guidance=True, negative_prompt=negative_prompt)
+        pe, ne = prompt_embeds[0], prompt_embeds[1]
+        pe = torch.cat([pe.to(ipe.device, self.dtype), ipe], dim=1)                             # :230-231
+        ne = torch.cat([ne.to(ipe.device, self.dtype), uipe], dim=1)
+        self.generator = get_generator(seed, kwargs.pop("generator_device", "cpu"))
+        return self.pipe(prompt_embeds=pe, negative_prompt_embeds=ne, guidance_scale=guidance_scale,
+                         num_inference_steps=num_inference_steps, generator=self.generator, **kwargs).images
 
     # shared tail of the generate() variants
     def _run(self, image_prompt_embeds, uncond_image_prompt_embeds, prompt, negative_prompt, num_samples, seed,
@@ -186,6 +221,41 @@ class IPAdapterXL(IPAdapter):
         ipe, uipe = self.get_image_embeds(pil_image=pil_image, clip_image_embeds=clip_image_embeds,
                                           extra_prompt_embeds=extra_prompt_embeds)
         return self._run(ipe, uipe, prompt, negative_prompt, num_samples, seed, num_inference_steps, prompt_embeds, kwargs)
+
+
+class IPAdapterPlus(IPAdapter):
+    """ip_adapter.py:344-374: Resampler (12 heads, width = the UNet's cross-attention dim) over the penultimate CLIP
+    hidden states; base ``generate``."""
+
+    def init_proj(self):                                                  # ip_adapter.py:347-360
+        cd = self.pipe.unet.config.cross_attention_dim
+        return Resampler(dim=cd, depth=4, dim_head=64, heads=12, num_queries=self.num_tokens,
+                         embedding_dim=self.clip_hidden_size, output_dim=cd, ff_mult=4).to(self.device, dtype=self.dtype)
+
+    @torch.inference_mode()
+    def get_image_embeds(self, pil_image=None, clip_image_embeds=None, uncond_clip_image_embeds=None):      # :362-374
+        """clip_image_embeds here = penultimate hidden states [B, 257, hidden] (as upstream names them); without an
+        attached CLIP model pass them together with ``uncond_clip_image_embeds`` (hidden states of a zero image)."""
+        if pil_image is not None:
+            if self.image_encoder is None or self.clip_image_processor is None:
+                raise NotImplementedError("CLIP image encoder not attached: pass clip_image_embeds (hidden states)")
+            imgs = pil_image if isinstance(pil_image, (list, tuple)) else [pil_image]
+            px = self.clip_image_processor(images=imgs, return_tensors="pt").pixel_values.to(self.device, dtype=self.dtype)
+            clip_image_embeds = self.image_encoder(px, output_hidden_states=True).hidden_states[-2]
+            uncond_clip_image_embeds = self.image_encoder(torch.zeros_like(px), output_hidden_states=True).hidden_states[-2]
+        if uncond_clip_image_embeds is None:
+            raise NotImplementedError("pass uncond_clip_image_embeds (CLIP hidden states of an all-zero image)")
+        c = clip_image_embeds.to(self.device, self.dtype)
+        u = uncond_clip_image_embeds.to(self.device, self.dtype)
+        return self.image_proj_model(c), self.image_proj_model(u)
+
+
+class IPAdapterFull(IPAdapterPlus):
+    """ip_adapter.py:377-386: every hidden-state token through the MLP projection."""
+
+    def init_proj(self):
+        return MLPProjModel(cross_attention_dim=self.pipe.unet.config.cross_attention_dim,
+                            clip_embeddings_dim=self.clip_hidden_size).to(self.device, dtype=self.dtype)
 
 
 class IPAdapterPlusXL(IPAdapter):

@@ -1,5 +1,5 @@
 """Conditioning modules of the reference on the HIP path (they run once per image, before the
-denoise loop): ImageProjModel (ip_adapter/ip_adapter.py:28-48), Cross_Attention
+denoise loop): ImageProjModel / MLPProjModel (ip_adapter/ip_adapter.py:28-66), Cross_Attention
 (ip_adapter/attention_processor.py:12-56), HarmonyAttention (train.py:188-266, the
 ``cross_attention`` fusion that training and test.py use) and the Resampler
 (ip_adapter/resampler.py:13-158).  Same constructor arguments and state-dict keys as the reference
@@ -44,6 +44,24 @@ class ImageProjModel(nn.Module):
         x = image_embeds.reshape(-1, image_embeds.shape[-1]).contiguous()
         t = _lin(ctx, self.proj, x).view(-1, self.cross_attention_dim)
         return _ln(ctx, self.norm, t).view(-1, self.clip_extra_context_tokens, self.cross_attention_dim)
+
+
+class MLPProjModel(nn.Module):
+    """IPAdapterFull's projection (ip_adapter/ip_adapter.py:50-66): Linear -> GELU(erf) -> Linear -> LayerNorm on every
+    CLIP hidden-state token; the GELU rides in the first GEMM's epilogue."""
+
+    def __init__(self, cross_attention_dim=1024, clip_embeddings_dim=1024):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(clip_embeddings_dim, clip_embeddings_dim), nn.GELU(),
+                                  nn.Linear(clip_embeddings_dim, cross_attention_dim), nn.LayerNorm(cross_attention_dim))
+
+    @torch.no_grad()
+    def forward(self, image_embeds):
+        ctx = _ctx_for(image_embeds)
+        x = image_embeds.reshape(-1, image_embeds.shape[-1]).contiguous()
+        h = _lin(ctx, self.proj[0], x, flags=L.GF_ACT_GELU)
+        t = _lin(ctx, self.proj[2], h)
+        return _ln(ctx, self.proj[3], t).view(*image_embeds.shape[:-1], -1)
 
 
 class Cross_Attention(nn.Module):

@@ -98,6 +98,20 @@ def main():
         print("resampler", name, tuple(y.shape))
 
 
+MLP_CFG = dict(cross_attention_dim=768, clip_embeddings_dim=1280)     # IPAdapterFull on an SD-1.x UNet + ViT-H hidden states
+
+
+@torch.no_grad()
+def mlpproj_fixture():
+    """MLPProjModel (ip_adapter.py:50-66) run by the REFERENCE class on seeded weights / inputs."""
+    ref = refshim.load()
+    m = ref.MLPProjModel(**MLP_CFG)
+    det_fill(m, 43, prefix="mlp.")
+    x = det_randn((1, 64, MLP_CFG["clip_embeddings_dim"]), 47)       # 64 of the 257 hidden-state tokens: small fixture
+    torch.save({"out": m(x), "cfg": MLP_CFG}, os.path.join(OUT, "mlpproj.pt"))
+    print("mlpproj", tuple(m(x).shape))
+
+
 def unet_fixture():
     """Reduced-width UNet forward + 2-step DDIM/CFG trajectory produced by the ORACLE itself (diffusers cannot be
     executed here, so this pins the oracle against drift, not against the reference)."""

@@ -167,6 +167,19 @@ class ImageProjModel(nn.Module):
         return self.norm(t)
 
 
+class MLPProjModel(nn.Module):
+    """ip_adapter/ip_adapter.py:50-66 (IPAdapterFull's projection): Linear -> GELU(erf) -> Linear -> LayerNorm, applied
+    to every CLIP hidden-state token."""
+
+    def __init__(self, cross_attention_dim=1024, clip_embeddings_dim=1024):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(clip_embeddings_dim, clip_embeddings_dim), nn.GELU(),
+                                  nn.Linear(clip_embeddings_dim, cross_attention_dim), nn.LayerNorm(cross_attention_dim))
+
+    def forward(self, image_embeds):
+        return self.proj(image_embeds)
+
+
 # --------------------------------------------------------------------------
 # Resampler  (ip_adapter/resampler.py)
 # --------------------------------------------------------------------------

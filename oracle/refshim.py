@@ -97,6 +97,7 @@ def load():
         CNAttnProcessor2_0=ap.CNAttnProcessor2_0,
         Cross_Attention=ap.Cross_Attention, Resampler=rs.Resampler, get_generator=ut.get_generator,
         HarmonyAttention=ref_train.HarmonyAttention, ImageProjModel=ref_ipa.ImageProjModel,
+        MLPProjModel=ref_ipa.MLPProjModel,
         IPAdapterXL=ref_ipa.IPAdapterXL, IPAdapterPlusXL=ref_ipa.IPAdapterPlusXL)
     _cache["ns"] = ns
     return ns

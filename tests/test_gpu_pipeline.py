@@ -183,3 +183,55 @@ def test_ipadapter_plus_xl_generate_call_sequence():
     assert a.shape == (1, 4, 32, 32) and torch.isfinite(a).all()
     assert ip.image_proj_model(kw["clip_hidden_states"].to(DEV, dtype)).shape == (1, 16, cd)
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2e-2)])
+def test_mlpproj_matches_reference_golden(dtype, tol):
+    """MLPProjModel (IPAdapterFull, ip_adapter.py:50-66) on the HIP ops (GELU in the GEMM epilogue)"""
+    from imagharmony_amd.modules import MLPProjModel
+    from oracle.gen_golden import MLP_CFG
+    g = torch.load(os.path.join(GOLDEN, "mlpproj.pt"))
+    m = det_fill(MLPProjModel(**MLP_CFG), 43, prefix="mlp.").to(DEV, dtype)
+    y = m(det_randn((1, 64, MLP_CFG["clip_embeddings_dim"]), 47).to(DEV, dtype))
+    assert y.shape == g["out"].shape and rel_rms(y.float().cpu(), g["out"]) < tol
+
+
+def test_ipadapter_plus_and_full_surface():
+    """IPAdapterPlus / IPAdapterFull (ip_adapter.py:344-386): projection modules, state-dict keys and the base
+    generate() call sequence with injected CLIP hidden states (SD-1.x style pipe: 2-tuple encode_prompt)."""
+    import imagharmony_amd as pkg
+    from imagharmony_amd.modules import MLPProjModel, Resampler
+
+    class _Cfg:
+        cross_attention_dim = 256
+        block_out_channels = (64, 128, 256)
+
+    class _Pipe:
+        def __init__(self, unet):
+            self.unet = unet
+            self.calls = []
+
+        def to(self, device):
+            return self
+
+        def __call__(self, **kw):
+            self.calls.append(kw)
+            return type("O", (), {"images": ["img"] * kw["prompt_embeds"].shape[0]})()
+
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    pipe = _Pipe(hu)
+    plus = pkg.IPAdapterPlus(pipe, None, None, DEV, num_tokens=16, dtype=dtype, clip_hidden_size=128)
+    full = pkg.IPAdapterFull(pipe, None, None, DEV, num_tokens=65, dtype=dtype, clip_hidden_size=128)
+    assert isinstance(plus.image_proj_model, Resampler) and isinstance(full.image_proj_model, MLPProjModel)
+    assert list(full.image_proj_model.state_dict()) == ["proj.0.weight", "proj.0.bias", "proj.2.weight", "proj.2.bias",
+                                                        "proj.3.weight", "proj.3.bias"]
+    hid, hid0 = det_randn((1, 65, 128), 9).to(DEV, dtype), det_randn((1, 65, 128), 10).to(DEV, dtype)
+    a, b = plus.get_image_embeds(clip_image_embeds=hid, uncond_clip_image_embeds=hid0)
+    assert a.shape == b.shape == (1, 16, ocfg.cross_attention_dim) and torch.isfinite(a.float()).all()
+    pe, ne = det_randn((2, 77, ocfg.cross_attention_dim), 11).to(DEV, dtype), det_randn((2, 77, ocfg.cross_attention_dim), 12).to(DEV, dtype)
+    imgs = full.generate(clip_image_embeds=hid, uncond_clip_image_embeds=hid0, num_samples=2, seed=7, guidance_scale=7.5,
+                         num_inference_steps=3, prompt_embeds=(pe, ne))
+    kw = pipe.calls[-1]
+    assert len(imgs) == 2 and kw["prompt_embeds"].shape == (2, 77 + 65, ocfg.cross_attention_dim)
+    assert kw["guidance_scale"] == 7.5 and kw["num_inference_steps"] == 3 and "pooled_prompt_embeds" not in kw

@@ -47,3 +47,28 @@ def test_processor_state_dict_and_surface():
     assert IPAttnProcessor is IPAttnProcessor2_0
     with pytest.raises(TypeError):      # the reference signature takes no extra kwargs (attention_processor.py:364-371)
         p(None, None, foo=1)
+
+
+@pytest.mark.parametrize("case", ["c1280_t4", "c128_t32"])
+def test_controlnet_processor_and_attn_map_match_reference_golden(case):
+    """CNAttnProcessor2_0 (text-only cross-attention + plain self-attention, attention_processor.py:534-621) and the
+    optional `attn_map` side output of IPAttnProcessor2_0 (:443-444), both against the reference's own outputs"""
+    from imagharmony_amd.attention_processor import CNAttnProcessor, CNAttnProcessor2_0, IPAttnProcessor2_0
+    dtype = torch.float16
+    g = torch.load(os.path.join(GOLDEN, f"attn_{case}.pt"))
+    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    hs, ehs = attn_inputs(case)
+    hs, ehs = hs.to(DEV, dtype), ehs.to(DEV, dtype)
+    attn = make_attn(case, cross=True).to(DEV, dtype)
+    cn = CNAttnProcessor2_0(num_tokens=t)
+    assert CNAttnProcessor is CNAttnProcessor2_0 and not list(getattr(cn, "parameters", lambda: [])())
+    assert rel_rms(cn(attn, hs, encoder_hidden_states=ehs).float().cpu(), g["cn"]) < TOL[dtype]
+    sattn = make_attn(case, cross=False).to(DEV, dtype)
+    assert rel_rms(cn(sattn, hs).float().cpu(), g["self"]) < TOL[dtype]
+    p = det_fill(IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=False), 17, prefix="proc.").to(DEV, dtype)
+    p(attn, hs, encoder_hidden_states=ehs)
+    assert not hasattr(p, "attn_map")                       # off by default
+    p.store_attn_map = True
+    p(attn, hs, encoder_hidden_states=ehs)
+    assert p.attn_map.shape == g["attn_map"].shape
+    assert rel_rms(p.attn_map.float().cpu(), g["attn_map"]) < 3e-3

@@ -60,6 +60,16 @@ def test_harmony_and_imageproj_match_reference_golden():
         assert rel_rms(proj(torch.zeros_like(fused)), g["uncond_tokens"]) < TOL
 
 
+def test_mlpproj_matches_reference_golden():
+    """MLPProjModel (IPAdapterFull, ip_adapter.py:50-66) restatement vs the reference class's own output"""
+    from oracle.gen_golden import MLP_CFG
+    g = torch.load(os.path.join(GOLDEN, "mlpproj.pt"))
+    with torch.no_grad():
+        m = det_fill(om.MLPProjModel(**MLP_CFG), 43, prefix="mlp.")
+        y = m(det_randn((1, 64, MLP_CFG["clip_embeddings_dim"]), 47))
+    assert y.shape == g["out"].shape and rel_rms(y, g["out"]) < TOL
+
+
 @pytest.mark.parametrize("name,cfg", [("plusxl", RES_PLUSXL), ("testcfg", RES_TEST)])
 def test_resampler_matches_reference_golden(name, cfg):
     g = torch.load(os.path.join(GOLDEN, f"resampler_{name}.pt"))
