@@ -7,6 +7,8 @@
 //   EW_CFG_STEP   CFG combine (custom_pipelines.py:348-350) + linear scheduler update
 //                 x' = cx*x + ce*eps (DDIM eta=0 / Euler), noise pred read
 //                 NHWC, latents kept NCHW fp32 (custom_pipelines.py:357)
+//   EW_CFG_RESCALE per-sample factor of rescale_noise_cfg (custom_pipelines.py:351-354; arXiv 2305.08891 3.4):
+//                 phi * std(eps_text) / std(eps_cfg) + (1 - phi), consumed by EW_CFG_STEP through `w`
 //   EW_CAST_F32   T -> fp32 copy (debug / host-side plumbing)
 //   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
 // Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
@@ -19,7 +21,7 @@
 namespace imh {
 
 enum : int { EW_TIMESTEP = 0, EW_SILU = 1, EW_CONCAT = 2, EW_CONV_IN = 3, EW_CFG_STEP = 4, EW_CAST_F32 = 5,
-             EW_ADD = 6, EW_STEP_SET = 7 };
+             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8 };
 
 // a: fp32 values [n_vals]; y: T [n_vals, dim]; cos first, then sin.
 template <typename T>
@@ -154,8 +156,42 @@ __global__ void cfg_step_kernel(const EwParams p) {
         } else {
             eps = to_f32(np_[((size_t)s * HW + pix) * 4 + ch]);
         }
+        if (p.w) eps *= ((const float*)p.w)[s];        // guidance_rescale factor of this sample (EW_CFG_RESCALE)
         if (p.b) ((float*)p.b)[i] = eps;
         lat[i] = cx * lat[i] + ce * eps;
+    }
+}
+
+// One workgroup per sample: unbiased std over (C, H, W) of the text-conditioned prediction and of the CFG
+// combination (torch.std semantics, as diffusers' rescale_noise_cfg), double accumulation, fixed-order tree.
+// a = noise prediction NHWC T [2S, HW, 4] ([uncond | cond]); y = fp32 [S]; f2 = guidance scale, f3 = guidance_rescale.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_rescale_kernel(const EwParams p) {
+    __shared__ double red[4][256];
+    const int S = p.i0, HW = p.i1, s = blockIdx.x;
+    const long long n = (long long)HW * 4;
+    const T* u = (const T*)p.a + (size_t)s * n;
+    const T* c = (const T*)p.a + (size_t)(S + s) * n;
+    double st = 0, st2 = 0, sc = 0, sc2 = 0;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float uu = to_f32(u[i]), cc = to_f32(c[i]);
+        const float g = uu + p.f2 * (cc - uu);
+        st += cc; st2 += (double)cc * cc; sc += g; sc2 += (double)g * g;
+    }
+    red[0][threadIdx.x] = st; red[1][threadIdx.x] = st2; red[2][threadIdx.x] = sc; red[3][threadIdx.x] = sc2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double N = (double)n;
+        const double vt = (red[1][0] - red[0][0] * red[0][0] / N) / (N - 1.0);
+        const double vc = (red[3][0] - red[2][0] * red[2][0] / N) / (N - 1.0);
+        const double ratio = sqrt(fmax(vt, 0.0)) / sqrt(fmax(vc, 1e-300));
+        ((float*)p.y)[s] = (float)(p.f3 * ratio + (1.0 - p.f3));
     }
 }
 
@@ -203,6 +239,10 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
         }
         case EW_CFG_STEP:
             hipLaunchKernelGGL((cfg_step_kernel<T>), dim3(grid_for((long long)p.i0 * p.i1 * 4, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_CFG_RESCALE:
+            if (p.i0 <= 0 || p.i1 <= 0) { set_error("cfg_rescale: empty problem"); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((cfg_rescale_kernel<T>), dim3(p.i0), dim3(256), 0, stream, p);
             break;
         case EW_CAST_F32:
             hipLaunchKernelGGL((cast_f32_kernel<T>), dim3(grid_for(p.n, 256)), dim3(256), 0, stream, p);

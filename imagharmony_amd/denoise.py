@@ -28,12 +28,19 @@ class DenoiseEngine:
     # -- conditioning (once per image / per PNS run; shared by every candidate seed) --
     @torch.no_grad()
     def set_conditioning(self, prompt_embeds, negative_prompt_embeds, pooled, negative_pooled, height, width,
-                         guidance_scale=5.0):
-        """prompt_embeds: [S, 77+T, 2048] (IP tokens already concatenated, ip_adapter.py:321-322)."""
+                         guidance_scale=5.0, guidance_rescale=0.0, original_size=None, crops_coords_top_left=(0, 0),
+                         target_size=None):
+        """prompt_embeds: [S, 77+T, 2048] (IP tokens already concatenated, ip_adapter.py:321-322).
+        original_size / crops_coords_top_left / target_size: SDXL micro-conditioning (custom_pipelines.py:277-293),
+        default (height, width), (0, 0), (height, width)."""
         self.do_cfg = guidance_scale > 1.0                                   # custom_pipelines.py:223
         self.guidance = float(guidance_scale)
+        if float(guidance_rescale) != getattr(self, "guidance_rescale", 0.0):
+            self.plan = None
+        self.guidance_rescale = float(guidance_rescale)                      # :351-354 (only with CFG)
         S = prompt_embeds.shape[0]
-        ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32).repeat(S, 1)   # :277-293
+        osz, tsz = tuple(original_size or (height, width)), tuple(target_size or (height, width))
+        ids = torch.tensor([list(osz) + list(crops_coords_top_left) + list(tsz)], dtype=torch.float32).repeat(S, 1)   # :277-293
         if self.do_cfg:                                                      # :295-298 -- order [uncond | cond]
             ehs = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
             text = torch.cat([negative_pooled, pooled], 0)
@@ -81,7 +88,7 @@ class DenoiseEngine:
         step counter, activation buffers and plan: lets several PNS candidates be in flight on one GPU (one HIP
         stream each), so that kernels of independent candidates fill the CUs a batch-1 kernel leaves idle."""
         e = DenoiseEngine(self.unet, self.device, self.dtype, self.use_graph)
-        for k in ("do_cfg", "guidance", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx"):
+        for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx"):
             setattr(e, k, getattr(self, k))
         st = StepState()
         src = self.st
@@ -98,7 +105,12 @@ class DenoiseEngine:
         rec = Ctx(self.device, self.dtype, record=True)
         out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
         rec.tag = 70
-        rec.ew(L.EW_CFG_STEP, st.latents, a=out, tab=st.coef_tab, step=st.step,
+        fac = None
+        if self.do_cfg and getattr(self, "guidance_rescale", 0.0) > 0.0:     # rescale_noise_cfg, custom_pipelines.py:351-354
+            fac = rec.new(self.S, dtype=torch.float32)
+            rec.ew(L.EW_CFG_RESCALE, fac, a=out, i=(self.S, self.H * self.W, 0, 0, 0, 0),
+                   f=(0.0, 0.0, self.guidance, self.guidance_rescale), descr="cfg.rescale")
+        rec.ew(L.EW_CFG_STEP, st.latents, a=out, w=fac, tab=st.coef_tab, step=st.step,
                i=(self.S, self.H * self.W, 0, int(self.do_cfg), 0, 0), f=(0.0, 0.0, self.guidance, 0.0), descr="cfg+step")
         rec.ew(L.EW_STEP_SET, st.step, i=(0, 0, 0, 0, 0, 0), descr="step++")
         if self.use_graph:
@@ -107,14 +119,18 @@ class DenoiseEngine:
         self.noise_pred = out
 
     @torch.no_grad()
-    def denoise(self, latents):
+    def denoise(self, latents, callback=None, callback_steps=1):
         """latents: [S, 4, H/8, W/8] unit-variance noise (CPU or device).  Returns final fp32 latents
-        (output_type='latent' of custom_pipelines.py:365-379)."""
+        (output_type='latent' of custom_pipelines.py:365-379).  callback(i, t, latents) every ``callback_steps``
+        steps (:359-363) is the only thing that makes the host wait inside the loop."""
         if self.plan is None:
             self._record()
         st = self.st
         st.latents.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)     # prepare_latents :255-265
         self.eager.ew(L.EW_STEP_SET, st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
-        for _ in range(self.steps):                                         # :325 -- no host work per step
+        for i in range(self.steps):                                         # :325 -- no host work per step
             self.plan.replay()
+            if callback is not None and i % callback_steps == 0:
+                torch.cuda.current_stream(self.device).synchronize()
+                callback(i, st.t_table[i].item(), st.latents)
         return st.latents

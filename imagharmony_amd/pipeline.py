@@ -71,9 +71,11 @@ class StableDiffusionXLCustomPipeline:
                  prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
                  negative_pooled_prompt_embeds=None, output_type: Optional[str] = "latent", return_dict: bool = True,
                  control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guidance_rescale: float = 0.0,
-                 **kwargs):
-        if guidance_rescale:
-            raise NotImplementedError("guidance_rescale > 0 (custom_pipelines.py:352-354) is not on the hot path")
+                 callback=None, callback_steps: int = 1, original_size=None, crops_coords_top_left=(0, 0),
+                 target_size=None, **kwargs):
+        if eta not in (0, 0.0):
+            raise NotImplementedError("eta != 0 (stochastic DDIM) is not supported: the device-resident step is the "
+                                      "deterministic x' = cx*x + ce*eps update (the reference runs eta = 0)")
         height = height or self.default_sample_size * self.vae_scale_factor      # :189-190
         width = width or self.default_sample_size * self.vae_scale_factor
         if prompt_embeds is None:
@@ -84,11 +86,12 @@ class StableDiffusionXLCustomPipeline:
         S = prompt_embeds.shape[0]
         eng = self.engine
         eng.set_conditioning(prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
-                             height, width, guidance_scale)
+                             height, width, guidance_scale, guidance_rescale=guidance_rescale, original_size=original_size,
+                             crops_coords_top_left=crops_coords_top_left, target_size=target_size)
         eng.set_schedule(self.scheduler, num_inference_steps, control_guidance_start, control_guidance_end)
         if latents is None:
             latents = randn_latents((S, 4, height // 8, width // 8), generator)       # prepare_latents :255-265
-        out = eng.denoise(latents).clone()
+        out = eng.denoise(latents, callback=callback, callback_steps=callback_steps).clone()
         if output_type != "latent":
             if self.vae_decode is None:
                 raise NotImplementedError("VAE decode / post-processing is the next row after the hot path "

@@ -37,9 +37,20 @@ def set_scale(unet, scale):
 
 
 @torch.no_grad()
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """diffusers 0.30.0 pipeline_stable_diffusion_xl.rescale_noise_cfg (third-party, absent here; imported by
+    custom_pipelines.py:6, called at :354): arXiv 2305.08891 section 3.4.  Per-sample unbiased std over (C, H, W)."""
+    dims = list(range(1, noise_pred_text.ndim))
+    std_text = noise_pred_text.std(dim=dims, keepdim=True)
+    std_cfg = noise_cfg.std(dim=dims, keepdim=True)
+    rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * rescaled + (1 - guidance_rescale) * noise_cfg
+
+
 def denoise(unet, scheduler, latents, prompt_embeds, negative_prompt_embeds, pooled, negative_pooled,
             height, width, num_inference_steps=30, guidance_scale=5.0,
-            control_guidance_start=0.0, control_guidance_end=1.0, trace=None):
+            control_guidance_start=0.0, control_guidance_end=1.0, trace=None, guidance_rescale=0.0,
+            original_size=None, crops_coords_top_left=(0, 0), target_size=None):
     """latents: [S,4,H/8,W/8] initial noise (already drawn on a CPU generator).
     prompt_embeds/negative_prompt_embeds: [S,77+T,2048]; pooled: [S,1280].
     Returns the final latents (output_type='latent')."""
@@ -47,7 +58,8 @@ def denoise(unet, scheduler, latents, prompt_embeds, negative_prompt_embeds, poo
     do_cfg = guidance_scale > 1.0                                              # :223
     scheduler.set_timesteps(num_inference_steps)                               # :250
     latents = latents * scheduler.init_noise_sigma                             # prepare_latents :255-265
-    tid = torch.tensor([[height, width, 0, 0, height, width]], dtype=prompt_embeds.dtype)   # :277-293
+    tid = torch.tensor([list(original_size or (height, width)) + list(crops_coords_top_left)
+                        + list(target_size or (height, width))], dtype=prompt_embeds.dtype)   # :277-293
     ehs, text, ids = prompt_embeds, pooled, tid.repeat(s, 1)
     if do_cfg:                                                                 # :295-298
         ehs = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
@@ -68,6 +80,8 @@ def denoise(unet, scheduler, latents, prompt_embeds, negative_prompt_embeds, poo
         if do_cfg:                                                             # :348-350
             u, c = eps.chunk(2)
             eps = u + guidance_scale * (c - u)
+            if guidance_rescale > 0.0:                                         # :351-354
+                eps = rescale_noise_cfg(eps, c, guidance_rescale)
         latents = scheduler.step(eps, t, latents)[0]                           # :357
         if trace is not None:
             trace.append(latents.clone())

@@ -37,7 +37,9 @@ def rel_rms(a, b):
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 
 
-def denoise_pair(device, dtype, steps=2, hw=32, guidance=5.0, scheduler="ddim", use_graph=True, cg_end=1.0):
+def denoise_pair(device, dtype, steps=2, hw=32, guidance=5.0, scheduler="ddim", use_graph=True, cg_end=1.0, **extra):
+    """extra: guidance_rescale / original_size / crops_coords_top_left / target_size, passed to both sides;
+    callback / callback_steps to the HIP pipeline only"""
     from imagharmony_amd import schedulers as hs
     from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
     from oracle.schedulers import EulerDiscreteScheduler as OracleEuler
@@ -47,12 +49,13 @@ def denoise_pair(device, dtype, steps=2, hw=32, guidance=5.0, scheduler="ddim", 
     po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
     osch = OracleDDIM() if scheduler == "ddim" else OracleEuler()
     ref = oracle_denoise(ou, osch, lat, pe, ne, po, no, hw * 8, hw * 8, num_inference_steps=steps,
-                         guidance_scale=guidance, control_guidance_end=cg_end)
+                         guidance_scale=guidance, control_guidance_end=cg_end,
+                         **{k: v for k, v in extra.items() if not k.startswith("callback")})
     pipe = StableDiffusionXLCustomPipeline(hu, scheduler=hs.DDIMScheduler() if scheduler == "ddim" else hs.EulerDiscreteScheduler(),
                                            device=device, dtype=dtype, use_graph=use_graph)
     out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
                height=hw * 8, width=hw * 8, num_inference_steps=steps, guidance_scale=guidance, latents=lat,
-               control_guidance_end=cg_end).images
+               control_guidance_end=cg_end, **extra).images
     return out.float().cpu(), ref
 
 

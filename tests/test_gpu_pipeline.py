@@ -30,6 +30,21 @@ def test_denoise_fp16_and_gating():
     assert (ref - ref2).abs().max() > 1e-4 and rel_rms(out2, ref2) < 1e-2
 
 
+def test_denoise_guidance_rescale_microconditioning_and_callback():
+    """rescale_noise_cfg (custom_pipelines.py:351-354) as a device-side per-sample factor, SDXL micro-conditioning
+    time_ids (:277-293) and the step callback (:359-363), against the oracle loop"""
+    seen = []
+    out, ref = denoise_pair(DEV, torch.bfloat16, steps=3, guidance=7.0, guidance_rescale=0.7, original_size=(512, 384),
+                            crops_coords_top_left=(16, 32), target_size=(256, 256),
+                            callback=lambda i, t, lat: seen.append((i, float(t), lat.float().abs().mean().item())),
+                            callback_steps=2)
+    r = rel_rms(out, ref)
+    assert torch.isfinite(out).all() and r < 3e-2, r
+    assert [s[0] for s in seen] == [0, 2] and seen[0][1] > seen[1][1] and all(s[2] > 0 for s in seen)
+    plain, ref_plain = denoise_pair(DEV, torch.bfloat16, steps=3, guidance=7.0)
+    assert rel_rms(ref, ref_plain) > 1e-2 and rel_rms(out, plain) > 1e-2        # the options really change the result
+
+
 def test_denoise_is_deterministic_and_replayable():
     a, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
     b, _ = denoise_pair(DEV, torch.bfloat16, steps=2)

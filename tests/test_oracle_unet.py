@@ -106,3 +106,18 @@ def test_oracle_unet_matches_its_committed_fixture():
     for k in g:
         a, b = now[k].float(), g[k].float()
         assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) < 2e-3, k
+
+
+def test_rescale_noise_cfg_closed_form():
+    """restated diffusers rescale_noise_cfg (arXiv 2305.08891 3.4): phi = 1 gives the CFG prediction the per-sample
+    std of the text-conditioned one; phi = 0 is the identity; samples are independent"""
+    from oracle.pipeline import rescale_noise_cfg
+    g = torch.Generator().manual_seed(0)
+    text = torch.randn(3, 4, 8, 8, generator=g) * torch.tensor([1.0, 2.0, 0.5]).view(3, 1, 1, 1)
+    cfg = torch.randn(3, 4, 8, 8, generator=g) * 3.0 + 0.2
+    full = rescale_noise_cfg(cfg, text, 1.0)
+    assert torch.allclose(full.flatten(1).std(1), text.flatten(1).std(1), rtol=1e-5)
+    assert torch.equal(rescale_noise_cfg(cfg, text, 0.0), cfg)
+    half = rescale_noise_cfg(cfg, text, 0.5)
+    assert torch.allclose(half, 0.5 * full + 0.5 * cfg, atol=1e-6)
+    assert torch.allclose(rescale_noise_cfg(cfg[1:2], text[1:2], 0.7), rescale_noise_cfg(cfg, text, 0.7)[1:2], atol=1e-6)
