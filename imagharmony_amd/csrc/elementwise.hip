@@ -9,6 +9,8 @@
 //                 NHWC, latents kept NCHW fp32 (custom_pipelines.py:357)
 //   EW_CFG_RESCALE per-sample factor of rescale_noise_cfg (custom_pipelines.py:351-354; arXiv 2305.08891 3.4):
 //                 phi * std(eps_text) / std(eps_cfg) + (1 - phi), consumed by EW_CFG_STEP through `w`
+//   EW_SOFTMAX    row softmax of fp32 scores -> T probabilities (the VAE mid-block attention: one head of width
+//                 512 over 4096-16384 tokens, materialised as GEMM -> softmax -> GEMM; once per image)
 //   EW_CAST_F32   T -> fp32 copy (debug / host-side plumbing)
 //   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
 // Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
@@ -21,7 +23,7 @@
 namespace imh {
 
 enum : int { EW_TIMESTEP = 0, EW_SILU = 1, EW_CONCAT = 2, EW_CONV_IN = 3, EW_CFG_STEP = 4, EW_CAST_F32 = 5,
-             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8 };
+             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8, EW_SOFTMAX = 9 };
 
 // a: fp32 values [n_vals]; y: T [n_vals, dim]; cos first, then sin.
 template <typename T>
@@ -195,6 +197,45 @@ __global__ __launch_bounds__(256) void cfg_rescale_kernel(const EwParams p) {
     }
 }
 
+// y[r, :] = softmax(f0 * a[r, :]) ; a fp32 [rows, ld_in], y T [rows, ld_out]; one workgroup per row, three passes
+// over a row that stays in L2 (<= 64 KB).  i0 rows, i1 cols (multiple of 4), i2 ld_in, i3 ld_out.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const EwParams p) {
+    __shared__ float red[4];
+    const int cols = p.i1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* a = (const float*)p.a + (size_t)blockIdx.x * p.i2;
+    T* y = (T*)p.y + (size_t)blockIdx.x * p.i3;
+    const float c = p.f0 * 1.4426950408889634f;
+    float m = -3.0e38f;
+    for (int i = threadIdx.x * 4; i < cols; i += 1024) {
+        const f32x4 v = *(const f32x4*)(a + i);
+        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float mc = m * c;       // f0 > 0: the maximum of the scaled row is the scaled maximum
+    float s = 0.f;
+    for (int i = threadIdx.x * 4; i < cols; i += 1024) {
+        const f32x4 v = *(const f32x4*)(a + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f(v[e] * c - mc);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x * 4; i < cols; i += 1024) {
+        const f32x4 v = *(const f32x4*)(a + i);
+        typename Vec<T>::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(__builtin_amdgcn_exp2f(v[e] * c - mc) * inv);
+        *(typename Vec<T>::v4*)(y + i) = o;
+    }
+}
+
 __global__ void step_set_kernel(int* step, int value, int set) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step = set ? value : *step + 1;
 }
@@ -243,6 +284,13 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
         case EW_CFG_RESCALE:
             if (p.i0 <= 0 || p.i1 <= 0) { set_error("cfg_rescale: empty problem"); return IMH_ERR_SHAPE; }
             hipLaunchKernelGGL((cfg_rescale_kernel<T>), dim3(p.i0), dim3(256), 0, stream, p);
+            break;
+        case EW_SOFTMAX:
+            if (p.i0 <= 0 || p.i1 <= 0 || (p.i1 & 3) || (p.i2 & 3) || (p.i3 & 3) || p.f0 <= 0.f) {
+                set_error("softmax: rows=%d cols=%d ld=%d/%d (cols and lds must be multiples of 4, scale > 0)", p.i0, p.i1, p.i2, p.i3);
+                return IMH_ERR_SHAPE;
+            }
+            hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3(p.i0), dim3(256), 0, stream, p);
             break;
         case EW_CAST_F32:
             hipLaunchKernelGGL((cast_f32_kernel<T>), dim3(grid_for(p.n, 256)), dim3(256), 0, stream, p);

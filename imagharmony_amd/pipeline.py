@@ -35,8 +35,12 @@ class StableDiffusionXLCustomPipeline:
     vae_scale_factor = 8
 
     def __init__(self, unet, scheduler=None, device="cuda:0", dtype=torch.bfloat16, vae_decode: Optional[Callable] = None,
-                 text_encoder: Optional[Callable] = None, use_graph=True):
+                 text_encoder: Optional[Callable] = None, use_graph=True, vae=None, watermark=None):
+        """vae: an ``imagharmony_amd.vae.AutoencoderKL`` (HIP decode + post-processing for output_type 'pil' / 'np' /
+        'pt'); ``vae_decode``: alternatively any callable latents -> images (its result is returned as is)."""
         self.unet = unet
+        self.vae = vae
+        self.watermark = watermark
         self.scheduler = scheduler or DDIMScheduler()
         self.device = torch.device(device)
         self.dtype = dtype
@@ -50,6 +54,15 @@ class StableDiffusionXLCustomPipeline:
         self.unet.to(self.device)
         self.engine = DenoiseEngine(self.unet, self.device, self.dtype, use_graph=self.engine.use_graph)
         return self
+
+    def enable_vae_tiling(self):                                          # test.py:73
+        if self.vae is None:
+            raise NotImplementedError("no VAE attached (construct the pipeline with vae=AutoencoderKL)")
+        self.vae.enable_tiling(True)
+
+    def disable_vae_tiling(self):
+        if self.vae is not None:
+            self.vae.enable_tiling(False)
 
     def set_scale(self, scale):                                           # custom_pipelines.py:17-20
         for p in self.unet.attn_processors.values():
@@ -92,9 +105,16 @@ class StableDiffusionXLCustomPipeline:
         if latents is None:
             latents = randn_latents((S, 4, height // 8, width // 8), generator)       # prepare_latents :255-265
         out = eng.denoise(latents, callback=callback, callback_steps=callback_steps).clone()
-        if output_type != "latent":
-            if self.vae_decode is None:
-                raise NotImplementedError("VAE decode / post-processing is the next row after the hot path "
-                                          "(SURVEY.md 8f-1): use output_type='latent' or pass vae_decode=callable")
-            out = self.vae_decode(out)
+        if output_type != "latent":                                       # custom_pipelines.py:365-386
+            if self.vae is not None:
+                from .vae import decode_latents, postprocess
+                image = decode_latents(self.vae, out)
+                if self.watermark is not None:
+                    image = self.watermark.apply_watermark(image)
+                out = postprocess(image, output_type)
+            elif self.vae_decode is not None:
+                out = self.vae_decode(out)
+            else:
+                raise NotImplementedError("no VAE attached: use output_type='latent', or construct the pipeline with "
+                                          "vae=imagharmony_amd.vae.AutoencoderKL(...) or vae_decode=callable")
         return StableDiffusionXLPipelineOutput(images=out) if return_dict else (out,)
