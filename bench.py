@@ -262,6 +262,27 @@ def main():
             ips, ok = run_stacked(a.stacked, 2, 1)
             res["stacked_candidates"] = {"per_forward": a.stacked, "images_per_sec": ips, "outputs_finite": ok,
                                          "note": f"UNet batch {2 * a.stacked} (CFG); same arithmetic per image as `value`"}
+        if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
+            try:
+                from imagharmony_amd.vae import AutoencoderKL, decode_latents
+                vae = AutoencoderKL().init_random_(1).to(device, dtype)
+                zl = out[:1].float() * 0.13025
+                ms_v = {}
+                for tiled in (False, True):
+                    vae.enable_tiling(tiled)
+                    img = decode_latents(vae, zl)
+                    torch.cuda.synchronize(device)
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        img = decode_latents(vae, zl)
+                    torch.cuda.synchronize(device)
+                    ms_v["tiled" if tiled else "untiled"] = (time.perf_counter() - t1) / 3 * 1e3
+                res["vae_decode"] = {"ms_per_image": ms_v, "outputs_finite": bool(torch.isfinite(img).all().item()),
+                                     "note": "SDXL VAE decoder 128x128 latent -> 1024x1024 image on the HIP kernels (random weights), "
+                                             "eager launches; not part of `value`"}
+                del vae
+            except Exception as e:      # noqa: BLE001
+                res["vae_decode"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_res, a.ip_tokens, a.denoise_steps)

