@@ -101,16 +101,8 @@ class IPAdapter:
 
     def load_ip_adapter(self, state_dict=None):                           # ip_adapter.py:135-154
         if state_dict is None:
-            if os.path.splitext(self.ip_ckpt)[-1] == ".safetensors":
-                from safetensors import safe_open
-                state_dict = {"image_proj": {}, "ip_adapter": {}, "composed_adapter": {}}
-                with safe_open(self.ip_ckpt, framework="pt", device="cpu") as f:
-                    for key in f.keys():
-                        for grp in state_dict:
-                            if key.startswith(grp + "."):
-                                state_dict[grp][key[len(grp) + 1:]] = f.get_tensor(key)
-            else:
-                state_dict = torch.load(self.ip_ckpt, map_location="cpu")
+            from .checkpoint import load_ip_adapter_file
+            state_dict = load_ip_adapter_file(self.ip_ckpt)
         self.image_proj_model.load_state_dict(state_dict["image_proj"])
         if self.number_class_crossattention is not None:
             self.number_class_crossattention.load_state_dict(state_dict["composed_adapter"])
