@@ -123,6 +123,8 @@ class AttnProcessor2_0(nn.Module):
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
         C_ = x.shape[1]
         H = attn.heads
+        if L_ % 64 and lk is None:
+            return self._emit_ragged(ctx, attn, x, B, L_, residual, ln, rowstats)
         if ln is None:
             wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
             g1, g2 = dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM)
@@ -142,6 +144,36 @@ class AttnProcessor2_0(nn.Module):
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
                        descr="self.to_out", rowstats=rowstats)
         ctx.free(qk); ctx.free(vt); ctx.free(ao)
+        return out
+
+    def _emit_ragged(self, ctx, attn, x, B, L_, residual, ln, rowstats):
+        """Token counts that are not a multiple of the 64-key tile (e.g. 1152x896 -> 36x28 = 1008 tokens at the
+        deepest level): every batch gets its own 64-padded slab of [Q|K] and V^T (dedicated zero-initialised
+        buffers, so the padded keys stay finite for ever; they are masked in the kernel), projections run per batch."""
+        if ln is not None or rowstats:
+            raise L.ImhError("ragged token counts are not supported together with the folded-LayerNorm path")
+        if L_ % 16:
+            raise L.ImhError(f"self-attention over {L_} tokens: the fused path needs a multiple of 16 "
+                             f"(the V^T layout permutes keys in groups of 16); use a resolution whose latent sides are even")
+        C_ = x.shape[1]
+        H = attn.heads
+        Lp = _pad64(L_)
+        wqk, wv, wo, bo = _packed_qk(attn, ctx), _w(attn.to_v, ctx), _w(attn.to_out[0], ctx), _b(attn.to_out[0], ctx)
+        qk = torch.zeros(B * Lp, 2 * C_, dtype=ctx.dtype, device=ctx.device)
+        vt = torch.zeros(C_, B * Lp, dtype=ctx.dtype, device=ctx.device)
+        ao = torch.zeros(B * Lp, C_, dtype=ctx.dtype, device=ctx.device)
+        if ctx.record:
+            ctx.keep.extend((qk, vt, ao))
+        for b in range(B):
+            xb = x[b * L_:(b + 1) * L_]
+            ctx.gemm(xb, wqk, out=qk[b * Lp:b * Lp + L_], descr="self.to_qk")
+            ctx.gemm(wv, xb, out=vt[:, b * Lp:b * Lp + L_], flags=L.GF_VT_PERM, descr="self.to_v^T")
+        ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, Lp, L_, Lp, 2 * C_, 2 * C_, B * Lp, C_,
+                      HEAD_DIM ** -0.5, descr="self.attn")
+        out = ctx.new(B * L_, C_)
+        for b in range(B):
+            ctx.gemm(ao[b * Lp:b * Lp + L_], wo, bias=bo, out=out[b * L_:(b + 1) * L_],
+                     residual=None if residual is None else residual[b * L_:(b + 1) * L_], descr="self.to_out")
         return out
 
     # -- eager plugin protocol ------------------------------------------------------------

@@ -65,7 +65,7 @@ class IPAdapter:
 
     def __init__(self, sd_pipe, image_encoder_path, ip_ckpt, device, num_tokens=4, target_blocks=None,
                  number_class_crossattention=None, image_encoder=None, dtype=torch.float16, clip_embeddings_dim=1280,
-                 clip_hidden_size=1280):
+                 clip_hidden_size=1280, clip_image_processor=None):
         self.device = device
         self.dtype = dtype
         self.image_encoder_path = image_encoder_path
@@ -74,7 +74,10 @@ class IPAdapter:
         self.pipe = sd_pipe.to(self.device)
         self.set_ip_adapter()
         self.image_encoder = image_encoder
-        self.clip_image_processor = None
+        self.clip_image_processor = clip_image_processor
+        if image_encoder is not None and clip_image_processor is None:
+            from transformers import CLIPImageProcessor                                     # ip_adapter.py:84
+            self.clip_image_processor = CLIPImageProcessor()
         if image_encoder is None and image_encoder_path is not None:
             from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection       # ip_adapter.py:81-84
             self.image_encoder = CLIPVisionModelWithProjection.from_pretrained(image_encoder_path).to(self.device, dtype=dtype)

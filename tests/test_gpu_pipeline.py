@@ -45,6 +45,30 @@ def test_denoise_guidance_rescale_microconditioning_and_callback():
     assert rel_rms(ref, ref_plain) > 1e-2 and rel_rms(out, plain) > 1e-2        # the options really change the result
 
 
+def test_denoise_non_square_ragged_token_count():
+    """256x320: the deepest level has 8x10 = 80 tokens -- not a multiple of the 64-key attention tile -- so the fused
+    self-attention takes its padded per-batch path (official SDXL sizes such as 1152x896 hit the same case: 36x28 = 1008)"""
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    from oracle.pipeline import denoise as oracle_denoise
+    from oracle.schedulers import DDIMScheduler as OracleDDIM
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    cd = ocfg.cross_attention_dim
+    lat = det_randn((1, 4, 32, 40), 3)
+    pe, ne = det_randn((1, 81, cd), 4), det_randn((1, 81, cd), 5)
+    po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
+    ref = oracle_denoise(ou, OracleDDIM(), lat, pe, ne, po, no, 256, 320, num_inference_steps=2, guidance_scale=5.0)
+    pipe = StableDiffusionXLCustomPipeline(hu, scheduler=hs.DDIMScheduler(), device=DEV, dtype=dtype)
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
+               height=256, width=320, num_inference_steps=2, guidance_scale=5.0, latents=lat).images
+    assert out.shape == (1, 4, 32, 40)
+    assert rel_rms(out.float().cpu(), ref) < 3e-2
+    with pytest.raises(Exception, match="multiple of 16"):          # 8x... tokens not a multiple of 16: a clear error, not garbage
+        pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
+             height=384, width=320, num_inference_steps=1, guidance_scale=5.0, latents=det_randn((1, 4, 48, 40), 3))
+
+
 def test_denoise_is_deterministic_and_replayable():
     a, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
     b, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
@@ -104,6 +128,47 @@ def test_ipadapterxl_generate_call_sequence():
     d = ip.generate(seed=43, scale=1.0, **kw)
     assert a.shape == (1, 4, 32, 32) and torch.isfinite(a).all()
     assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+
+
+def test_end_to_end_pil_in_pil_out_like_test_py():
+    """test.py's whole flow on reduced configs, nothing injected except prompt embeddings (no tokenizer vocabulary
+    offline): PIL image -> CLIPImageProcessor -> CLIP vision model (transformers, random weights; the step before
+    the path) -> HarmonyAttention + ImageProjModel -> IP tokens -> denoise -> VAE tiled decode ->
+    post-processing -> PIL image."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+    from imagharmony_amd.ip_adapter import IPAdapterPlusXL, IPAdapterXL
+    from imagharmony_amd.modules import HarmonyAttention
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    from imagharmony_amd.vae import AutoencoderKL, VAEConfig
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    vae = AutoencoderKL(VAEConfig(block_out_channels=(64, 64, 128, 128), layers_per_block=1, sample_size=256)).init_random_(2).to(DEV, dtype)
+    pipe = StableDiffusionXLCustomPipeline(hu, device=DEV, dtype=dtype, vae=vae)
+    pipe.enable_vae_tiling()
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                                          num_attention_heads=4, image_size=32, patch_size=8,
+                                                          projection_dim=128)).eval().to(DEV, dtype)
+    proc = CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32})
+    img = Image.fromarray((np.random.RandomState(0).rand(48, 40, 3) * 255).astype("uint8"))
+    cd = ocfg.cross_attention_dim
+    ha = det_fill(HarmonyAttention(image_hidden_size=128, text_context_dim=cd, inter_dim=512, cross_heads=8,
+                                   reshape_blocks=8, cross_value_dim=64), 3)
+    ip = IPAdapterXL(pipe, None, None, DEV, num_tokens=4, inference=True, number_class_crossattention=ha, dtype=dtype,
+                     image_encoder=clip, clip_image_processor=proc)
+    assert ip.clip_embeddings_dim == 128                       # read from the encoder's config (ip_adapter.py:93-95)
+    det_fill(ip.image_proj_model, 5)
+    embeds = (det_randn((1, 77, cd), 1), det_randn((1, 77, cd), 2), det_randn((1, ocfg.pooled_dim), 3),
+              det_randn((1, ocfg.pooled_dim), 4))
+    out = ip.generate(pil_image=img, prompt_embeds=embeds, extra_prompt_embeds=det_randn((1, 77, cd), 6), num_samples=1,
+                      seed=42, num_inference_steps=2, guidance_scale=5.0, height=256, width=320, output_type="pil")
+    assert isinstance(out[0], Image.Image) and out[0].size == (320, 256)
+    plus = IPAdapterPlusXL(pipe, None, None, DEV, num_tokens=16, dtype=dtype, image_encoder=clip, clip_image_processor=proc)
+    assert plus.clip_hidden_size == 64
+    a, b = plus.get_image_embeds(pil_image=img)                # penultimate hidden states -> Resampler (ip_adapter.py:405-417)
+    assert a.shape == b.shape == (1, 16, cd) and torch.isfinite(a.float()).all() and not torch.equal(a, b)
 
 
 def test_pns_single_rank_on_device():
