@@ -557,6 +557,11 @@ class UNet2DConditionModel(nn.Module):
         cfg = self.config
         B = 2 * S if cfg_dup else S
         boc = cfg.block_out_channels
+        div = 1 << (len(boc) - 1)
+        if Hl % div or Wl % div:
+            # diffusers interpolates the up path to the skip's size in that case (forward_upsample_size); the
+            # fused nearest-x2 upsampling here does not, so refuse instead of producing misaligned skips
+            raise L.ImhError(f"latent {Hl}x{Wl}: sides must be multiples of {div} (image sides multiples of {8 * div})")
         # -- time embedding --
         ctx.tag = 1
         tsin = ctx.new(B, boc[0])

@@ -143,24 +143,25 @@ def main():
     ap.add_argument("--lat", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--candidates", type=int, default=1, help="PNS candidates stacked per forward (UNet batch 2S)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
     a = ap.parse_args()
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
     os.makedirs(a.out, exist_ok=True)
     print(torch.cuda.get_device_name(0), flush=True)
     u = build_unet(dtype)
-    rec, out, st = record(u, dtype, a.lat)
+    rec, out, st = record(u, dtype, a.lat, S=a.candidates)
     ms, wall = time_plan(rec)
     results = [summarize(rec, ms, wall, "heuristic configs")]
     assert torch.isfinite(out.float()).all(), "non-finite UNet output"
     if not a.no_sweep:
         table, report = sweep_shapes(rec, dtype)
-        with open(os.path.join(a.out, "tuning.json"), "w") as f:
+        with open(os.path.join(a.out, f"tuning_s{a.candidates}.json" if a.candidates > 1 else "tuning.json"), "w") as f:
             json.dump(table, f, indent=0)
         with open(os.path.join(a.out, "sweep_report.json"), "w") as f:
             json.dump(report, f)
         tuned = {tuple(int(v) for v in k.split(",")): tuple(v) for k, v in table.items()}
-        rec2, out2, _ = record(u, dtype, a.lat, tuning=tuned)
+        rec2, out2, _ = record(u, dtype, a.lat, S=a.candidates, tuning=tuned)
         ms2, wall2 = time_plan(rec2)
         results.append(summarize(rec2, ms2, wall2, "tuned configs"))
         rec2.capture()
