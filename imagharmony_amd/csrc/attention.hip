@@ -20,7 +20,7 @@
 
 namespace imh {
 
-int g_attn_force_nw = 0;   // debugging / tuning override (imh_debug_set)
+int g_attn_force_nw = 0;   // retired tuning knob (imh_debug_set key 0): only the 4-wave workgroup is built
 
 constexpr int ATT_KV = 64;              // keys per LDS tile
 constexpr int ATT_TILE_BYTES = 64 * 128;
@@ -49,9 +49,7 @@ __device__ __forceinline__ float xhalf_max(float x) {
 #endif
 #define ATT_EXP2(x) ((ATT_ABL & 9) ? (x) : __builtin_amdgcn_exp2f(x))
 
-// NW waves per workgroup (32 queries each).  The grid is (ceil(Lq / (32 NW)), H, B): NW is picked by the
-// launcher so that the number of workgroups is a multiple of what the chip holds at once (SDXL: L=4096 ->
-// NW=2, L=1024 -> NW=1, both 1280 workgroups = 5 per CU), instead of 1.25 "rounds" of 4-wave workgroups.
+// NW waves per workgroup (32 queries each); the launcher uses NW = 4.
 // NPASS = 1: single key set (self-attention, text-only cross-attention): no second accumulator, lower register
 // pressure -> 3 workgroups per CU instead of 2.  NPASS = 2: text + image-prompt key sets.
 template <typename T, int NW, int NPASS>
@@ -361,16 +359,15 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     }
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("attention: empty problem"); return IMH_ERR_SHAPE; }
     if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
-    // 4 waves share every K / V^T tile; finer workgroups (NW = 1 | 2, kept for experiments through
-    // imh_debug_set) balance the grid better but re-read K/V and measured 25-50 % slower on MI355X.
-    int nw = g_attn_force_nw;
-    if (nw != 1 && nw != 2 && nw != 4) nw = 4;
+    // 4 waves (128 queries) share every K / V^T tile.  Finer workgroups (1 or 2 waves) balance the grid better but
+    // re-read K / V^T and measured 25-50 % slower on MI355X, so only this shape is built.
+    constexpr int nw = 4;
     const int items = ((p.Lq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
     dim3 grid(8 * ((items + 7) / 8));
 #define IMH_ATT_LAUNCH(TT, NWV) do { if (p.K2) hipLaunchKernelGGL((attn_kernel<TT, NWV, 2>), grid, dim3(64 * NWV), 0, stream, p); \
         else hipLaunchKernelGGL((attn_kernel<TT, NWV, 1>), grid, dim3(64 * NWV), 0, stream, p); } while (0)
-    if (dtype == IMH_DT_BF16) { if (nw == 4) IMH_ATT_LAUNCH(bf16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(bf16_t, 2); else IMH_ATT_LAUNCH(bf16_t, 1); }
-    else { if (nw == 4) IMH_ATT_LAUNCH(f16_t, 4); else if (nw == 2) IMH_ATT_LAUNCH(f16_t, 2); else IMH_ATT_LAUNCH(f16_t, 1); }
+    if (dtype == IMH_DT_BF16) IMH_ATT_LAUNCH(bf16_t, 4);
+    else IMH_ATT_LAUNCH(f16_t, 4);
 #undef IMH_ATT_LAUNCH
     return check_launch("attn_kernel");
 }

@@ -251,7 +251,7 @@ int imh_plan_time_ops(imh_plan* p, void* stream, float* ms, int n);
 int imh_plan_get_tag(const imh_plan* p, int index);
 int imh_plan_get_kind(const imh_plan* p, int index);
 
-/* tuning / debugging knobs -- key 0: attention waves per workgroup (1|2|4, 0 = default 4);
+/* tuning / debugging knobs -- key 0: retired (attention workgroups are always 4 waves; accepted and ignored);
  * key 2: XCD tile placement (0 auto, 1 legacy row-major, 2..5 force the (8,1) (4,2) (2,4) (1,8) partition) */
 int imh_debug_set(int key, int value);
 

@@ -15,7 +15,6 @@ for (B,H,L) in [(2,10,4096),(2,20,1024),(8,10,4096),(8,20,1024)]:
     line=f"self B={B} H={H} L={L}:"
     ref=None
     for nw in (4,):
-        ctx.lib.imh_debug_set(0,nw)
         f=lambda: ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, L, L, L, 2*C_, 2*C_, B*L, C_, 0.125)
         ms=timeit(f)
         if ref is None: ref=out.clone()
@@ -29,7 +28,6 @@ for (B,H,L) in [(2,20,1024),(2,10,4096)]:
     v=torch.zeros(B,128,C_,device=DEV,dtype=dtype); v[:,:77]=torch.randn(B,77,C_,device=DEV).to(dtype); vt=make_vt(v,128); out=torch.empty(B*L,C_,device=DEV,dtype=dtype)
     line=f"cross B={B} H={H} L={L}:"
     for nw in (4,):
-        ctx.lib.imh_debug_set(0,nw)
         ms=timeit(lambda: ctx.attention(q,k,vt,out,B,H,L,77,128,C_,C_,B*128,C_,0.125))
         line+=f"  [nw={nw} {ms*1e3:.1f}us {2*B*L*C_*2*2/ms/1e6:.0f}GB/s]"
     print(line,flush=True)
