@@ -223,6 +223,9 @@ def main():
         n_g = sum(1 for t in rec.tags if t[1] == L.OP_GEMM)
         tot_fl = sum(t[3] for t in rec.tags)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
+        a_fl = sum(t[3] for t, m in zip(rec.tags, ms) if t[1] == L.OP_ATTN)
+        a_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_ATTN)
+        n_a = sum(1 for t in rec.tags if t[1] == L.OP_ATTN)
         # HBM bytes per launch of the family from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
@@ -251,6 +254,12 @@ def main():
                          "launches_per_step": n_g, "avg_launch_us": g_ms / n_g * 1e3,
                          "algorithmic_tflop_per_step": g_fl / 1e12,
                          "whole_forward_tflops": tot_fl / (dt / a.steps / a.denoise_steps) / 1e12},
+            # second kernel family, same method (HIP events on the launch stream): the flash / decoupled-IP attention
+            "roofline_attention": {"bound": "mfma", "achieved": a_fl / (a_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                   "frac": a_fl / (a_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::attn_kernel (self + text/IP cross)",
+                                   "launches_per_step": n_a, "avg_launch_us": a_ms / n_a * 1e3,
+                                   "algorithmic_tflop_per_step": a_fl / 1e12,
+                                   "note": "head_dim 64: softmax VALU time adds to MFMA time on a SIMD (profiles/r01_pmc_sq_gemm_attn.md)"},
         }
         if world == 1 and a.in_flight > 1:
             # extra, NOT the headline: several batch-1 candidates in flight on the one GPU (what PNS does with N > n_gpus)
