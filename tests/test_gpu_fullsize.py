@@ -90,3 +90,29 @@ def test_fullsize_vae_decode_1024():
     t = decode_latents(vae, lat)
     assert t.shape == a.shape and torch.isfinite(t).all() and not torch.equal(t, a)
     assert postprocess(t, "pil")[0].size == (1024, 1024)
+
+
+@pytest.mark.parametrize("dtype,S,T,sched", [(torch.float16, 4, 16, "euler"), (torch.bfloat16, 4, 32, "ddim")])
+def test_fullsize_stacked_candidates_configs_3_and_4(dtype, S, T, sched):
+    """BASELINE.json configs[3] (batch 4 per GPU, 16 Resampler tokens, fp16) and configs[4] (4 PNS candidates per GPU,
+    2 x 16 image tokens; its fp8 attention is not built -- bf16 here) at the full SDXL size: S candidates stacked
+    into one UNet batch of 2S.  Properties: finite; every candidate equals its own batch-1 run up to rounding
+    (candidates are independent rows of every op); identical candidates give bitwise identical rows."""
+    import bench
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    unet = bench.build_unet(DEV, dtype, T)
+    mk = (lambda: hs.EulerDiscreteScheduler()) if sched == "euler" else (lambda: hs.DDIMScheduler())
+    pipe = StableDiffusionXLCustomPipeline(unet, scheduler=mk(), device=DEV, dtype=dtype)
+    pe, ne, po, no = [t.to(DEV) for t in bench.synthetic_conditioning(T)]
+    z = torch.randn(S, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(11))
+    z[3] = z[0]                                                                     # candidate 3 == candidate 0
+    kw = dict(height=1024, width=1024, num_inference_steps=2, guidance_scale=5.0)
+    stacked = pipe(prompt_embeds=pe.repeat(S, 1, 1), negative_prompt_embeds=ne.repeat(S, 1, 1),
+                   pooled_prompt_embeds=po.repeat(S, 1), negative_pooled_prompt_embeds=no.repeat(S, 1), latents=z, **kw).images.clone()
+    assert stacked.shape == (S, 4, 128, 128) and torch.isfinite(stacked).all()
+    assert torch.equal(stacked[3], stacked[0]) and not torch.equal(stacked[1], stacked[0])
+    one = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
+               latents=z[1:2], **kw).images
+    rel = ((stacked[1:2] - one).pow(2).mean().sqrt() / one.pow(2).mean().sqrt()).item()
+    assert rel < (1e-2 if dtype == torch.float16 else 3e-2), rel
