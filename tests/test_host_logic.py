@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 import torch
 
@@ -144,3 +145,54 @@ def test_unet_checkpoint_roundtrip_with_oracle_schema(tmp_path):
     save_file(bad, str(tmp_path / "bad.safetensors"))
     with pytest.raises(KeyError):
         UNet2DConditionModel.from_safetensors(str(tmp_path / "bad.safetensors"), cfg)
+
+
+def test_header_enums_match_python_constants():
+    """IMH_EW_* / IMH_GF_* / IMH_OP_* values in include/imh.h == the constants imagharmony_amd/lib.py hands to the ABI"""
+    from imagharmony_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    vals.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s+(\d+)", hdr)})
+    assert len([k for k in vals if k.startswith("IMH_EW_")]) == 10
+    for k, v in vals.items():
+        py = k[len("IMH_"):]
+        if hasattr(lib, py):
+            assert getattr(lib, py) == v, k
+    for name in ("EW_TIMESTEP", "EW_CONV_IN", "EW_CFG_STEP", "EW_STEP_SET", "EW_CFG_RESCALE", "EW_SOFTMAX"):
+        assert vals["IMH_" + name] == getattr(lib, name)
+
+
+def test_vae_host_plumbing_matches_oracle_on_cpu(tmp_path):
+    """the tile blends of the HIP VAE's tiled_decode are host-side torch: they must equal diffusers' in-place
+    blend_v / blend_h (restated in oracle.vae), and the holder must take an oracle / diffusers state dict strictly"""
+    from imagharmony_amd.vae import AutoencoderKL, VAEConfig, postprocess
+    from oracle.detfill import det_fill, det_randn
+    from oracle.vae import AutoencoderKL as OracleVAE
+    from oracle.vae import postprocess as oracle_post
+    from oracle.vae import tiny_vae_config
+    a, b = det_randn((2, 3, 40, 24), 1), det_randn((2, 3, 40, 24), 2)
+    for dim, fn in ((2, OracleVAE.blend_v), (3, OracleVAE.blend_h)):
+        for extent in (8, 64):
+            want = fn(a.clone(), b.clone(), extent)
+            got = AutoencoderKL._blend(a.clone(), b.clone(), extent, dim)
+            assert torch.allclose(got, want, atol=1e-6), (dim, extent)
+    ocfg = tiny_vae_config()
+    ov = det_fill(OracleVAE(ocfg), 3)
+    hv = AutoencoderKL(VAEConfig(**{k: getattr(ocfg, k) for k in VAEConfig.__dataclass_fields__}))
+    missing, unexpected = hv.load_state_dict(ov.state_dict(), strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(hv.decoder.mid_block.attentions[0].to_q.weight, ov.decoder.mid_block.attentions[0].to_q.weight)
+    assert hv.tile_latent_min_size == ov.tile_latent_min_size == 32
+    img = det_randn((1, 3, 16, 16), 4) * 2
+    assert np.array_equal(postprocess(img, "np"), oracle_post(img, "np"))
+    assert np.array_equal(np.asarray(postprocess(img, "pil")[0]), np.asarray(oracle_post(img, "pil")[0]))
+    with pytest.raises(ValueError):
+        postprocess(img, "jpeg")
+
+
+def test_pipeline_argument_checks_need_no_gpu():
+    """eta != 0 is refused (the device-resident step is the deterministic update)"""
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    pipe = StableDiffusionXLCustomPipeline.__new__(StableDiffusionXLCustomPipeline)
+    with pytest.raises(NotImplementedError, match="eta"):
+        pipe(prompt_embeds=torch.zeros(1, 81, 8), eta=0.5)
