@@ -7,7 +7,7 @@ from imagharmony_amd.schedulers import DDIMScheduler
 DEV = torch.device("cuda:0"); dtype = torch.bfloat16
 unet = bench.build_unet(DEV, dtype, 4)
 pe, ne, po, no = [t.to(DEV) for t in bench.synthetic_conditioning(4)]
-for S in (1, 2, 4):
+for S in (1, 2, 4, 8):
     pipe = StableDiffusionXLCustomPipeline(unet, scheduler=DDIMScheduler(), device=DEV, dtype=dtype)
     eng = pipe.engine
     eng.set_conditioning(pe.repeat(S, 1, 1), ne.repeat(S, 1, 1), po.repeat(S, 1), no.repeat(S, 1), 1024, 1024, guidance_scale=5.0)
