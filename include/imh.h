@@ -203,8 +203,9 @@ enum imh_ew_op {
     IMH_EW_CAST_F32 = 5,
     IMH_EW_ADD = 6,
     IMH_EW_STEP_SET = 7,  /* *y(int32) = i1 ? i0 : *y + 1 : the device-side step counter */
-    IMH_EW_SOFTMAX = 9,   /* y[r,:] (T) = softmax(f0 * a[r,:]) (fp32); i0 rows, i1 cols, i2 / i3 leading dims */
-    IMH_EW_CFG_RESCALE = 8 /* y[s] = f3 * std(eps_text_s) / std(eps_cfg_s) + 1 - f3 (custom_pipelines.py:351-354); EW_CFG_STEP reads it via `w` */
+    IMH_EW_CFG_RESCALE = 8, /* y[s] = f3 * std(eps_text_s) / std(eps_cfg_s) + 1 - f3 (rescale_noise_cfg, custom_pipelines.py:351-354);
+                             * a = noise prediction NHWC [2 i0, i1, 4], f2 = guidance scale; IMH_EW_CFG_STEP reads y through `w` */
+    IMH_EW_SOFTMAX = 9      /* y[r,:] (T) = softmax(f0 * a[r,:]) with a fp32 (VAE mid-block attention); i0 rows, i1 cols, i2 / i3 leading dims */
 };
 
 typedef struct imh_ew_args {
