@@ -116,3 +116,21 @@ def test_fullsize_stacked_candidates_configs_3_and_4(dtype, S, T, sched):
                latents=z[1:2], **kw).images
     rel = ((stacked[1:2] - one).pow(2).mean().sqrt() / one.pow(2).mean().sqrt()).item()
     assert rel < (1e-2 if dtype == torch.float16 else 3e-2), rel
+
+
+def test_fullsize_replay_race_screen(sdxl):
+    """race screen for the LDS-DMA pipelines (counted vmcnt + raw barriers): 40 replays of the full-size forward
+    (968 kernel launches each, every tile shape of the table) must be bitwise identical -- an early LDS read or a
+    late restage shows up as a tile that differs between runs"""
+    pipe, (pe, ne, po, no) = sdxl
+    eng = pipe.engine
+    eng.set_conditioning(pe, ne, po, no, 1024, 1024, guidance_scale=5.0)
+    eng.set_schedule(pipe.scheduler, 1)
+    z = torch.randn(1, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(5))
+    first = eng.denoise(z).clone()
+    npred = eng.noise_pred.clone()
+    assert torch.isfinite(first).all()
+    for i in range(40):
+        out = eng.denoise(z)
+        assert torch.equal(out, first), f"replay {i} differs"
+    assert torch.equal(eng.noise_pred, npred)
