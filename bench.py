@@ -263,14 +263,20 @@ def main():
         }
         if world == 1 and a.in_flight > 1:
             # extra, NOT the headline: several batch-1 candidates in flight on the one GPU (what PNS does with N > n_gpus)
-            res["concurrent_candidates"] = {"in_flight": a.in_flight, "images_per_sec": run_concurrent(a.in_flight, 2, 1),
-                                            "note": "independent batch-1 denoises on separate HIP streams sharing weights and "
-                                                    "conditioning; same arithmetic per image as `value`"}
+            try:
+                res["concurrent_candidates"] = {"in_flight": a.in_flight, "images_per_sec": run_concurrent(a.in_flight, 2, 1),
+                                                "note": "independent batch-1 denoises on separate HIP streams sharing weights and "
+                                                        "conditioning; same arithmetic per image as `value`"}
+            except Exception as e:      # noqa: BLE001  -- extras must never cost the headline number
+                res["concurrent_candidates"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:
             # extra, NOT the headline: the rank's candidates as one UNet batch (PNS with N > n_gpus, configs[4])
-            ips, ok = run_stacked(a.stacked, 2, 1)
-            res["stacked_candidates"] = {"per_forward": a.stacked, "images_per_sec": ips, "outputs_finite": ok,
-                                         "note": f"UNet batch {2 * a.stacked} (CFG); same arithmetic per image as `value`"}
+            try:
+                ips, ok = run_stacked(a.stacked, 2, 1)
+                res["stacked_candidates"] = {"per_forward": a.stacked, "images_per_sec": ips, "outputs_finite": ok,
+                                             "note": f"UNet batch {2 * a.stacked} (CFG); same arithmetic per image as `value`"}
+            except Exception as e:      # noqa: BLE001
+                res["stacked_candidates"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
             try:
                 from imagharmony_amd.vae import AutoencoderKL, decode_latents
