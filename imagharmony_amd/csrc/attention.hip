@@ -48,6 +48,16 @@ __device__ __forceinline__ float xhalf_max(float x) {
 #define ATT_ABL 0
 #endif
 #define ATT_EXP2(x) ((ATT_ABL & 9) ? (x) : __builtin_amdgcn_exp2f(x))
+// ATT_TIMING (tools/attn_phase_probe.py only): cycle counter at the phase boundaries of the key loop; work item 0 /
+// thread 0 writes the per-phase totals (+ tile count) to p.pf_ptr instead of prefetching
+#ifndef ATT_TIMING
+#define ATT_TIMING 0
+#endif
+#if ATT_TIMING
+#define ATT_TICK(i) do { asm volatile("s_nop 0" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[i] += tn_ - tm0; tm0 = tn_; } while (0)
+#else
+#define ATT_TICK(i) do {} while (0)
+#endif
 
 // NW waves per workgroup (32 queries each); the launcher uses NW = 4.
 // NPASS = 1: single key set (self-attention, text-only cross-attention): no second accumulator, lower register
@@ -148,17 +158,22 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
         for (int s = 0; s < ATT_STAGES - 1; ++s)
             if (s < ntiles) stage(s, s);
         int cur = 0;
+#if ATT_TIMING
+        unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tm0 = __builtin_readcyclecounter();
+#endif
         for (int t = 0; t < ntiles; ++t) {
             if (ATT_ABL & 16) {
             } else if (t + ATT_STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ATT_STAGES - 2) * LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ATT_ABL & 4)) __builtin_amdgcn_s_barrier();      // tile t landed for every wave; tile t-1 fully consumed
             asm volatile("" ::: "memory");
+            ATT_TICK(0);       // vmcnt wait + barrier
             if (!(ATT_ABL & 2) && t + ATT_STAGES - 1 < ntiles) {
                 int ns = cur + ATT_STAGES - 1;
                 if (ns >= ATT_STAGES) ns -= ATT_STAGES;
                 stage(ns, (ATT_ABL & 32) ? 0 : t + ATT_STAGES - 1);
             }
+            ATT_TICK(1);       // LDS-DMA issue
             const unsigned char* ks = smem + cur * 2 * ATT_TILE_BYTES;
             const unsigned char* vs = ks + ATT_TILE_BYTES;
             const int kbase = t * ATT_KV;
@@ -185,6 +200,7 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            ATT_TICK(2);       // K fragment reads + QK^T MFMA issue
             v8 vf[2][2][2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -239,15 +255,24 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
             l_run += ps2[0] + ps2[1];
             // ---- O^T += V^T P^T ----
             __builtin_amdgcn_sched_barrier(0);
+            ATT_TICK(3);       // V^T read issue + MFMA drain + softmax
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s][dt], pf[kt][s], o[dt]);
+            ATT_TICK(4);       // PV MFMA issue
             asm volatile("" ::: "memory");
             if (++cur == ATT_STAGES) cur = 0;
         }
+#if ATT_TIMING
+        if (item == 0 && tid == 0 && p.pf_ptr) {
+            unsigned long long* dbg = (unsigned long long*)p.pf_ptr;
+            for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
+            dbg[5] = ntiles;
+        }
+#endif
         __builtin_amdgcn_s_barrier();          // the next pass refills the ring from slot 0
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = wgt / l_tot;
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
                 *(v8*)((T*)p.O + ((size_t)b * p.Lq + q0 + r2) * p.ldo + h * 64 + ch * 8) = o8;
         }
     }
-    tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+    if (!ATT_TIMING) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
 }
 
 // ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
