@@ -61,11 +61,17 @@ class DenoiseEngine:
         return st
 
     # -- schedule tables --
-    def set_schedule(self, scheduler, num_inference_steps, control_guidance_start=0.0, control_guidance_end=1.0):
+    def set_schedule(self, scheduler, num_inference_steps, control_guidance_start=0.0, control_guidance_end=1.0,
+                     denoising_end=None):
         scheduler.set_timesteps(num_inference_steps)
         tab = scheduler.tables()
         st, dev = self.st, self.device
         n = num_inference_steps
+        if denoising_end is not None and isinstance(denoising_end, float) and 0 < denoising_end < 1:
+            # custom_pipelines.py:303-311: stop once t falls below the cut-off; the gating window below then counts
+            # the truncated list, as upstream does
+            cutoff = int(round(1000 - denoising_end * 1000))
+            n = int((tab["timesteps"] >= cutoff).sum().item())
         st.t_table = tab["timesteps"].to(dev)
         st.coef_tab = tab["coef"].contiguous().to(dev)
         new_in = tab["in_scale"].to(dev) if tab["in_scale"] is not None else None

@@ -85,10 +85,13 @@ class StableDiffusionXLCustomPipeline:
                  negative_pooled_prompt_embeds=None, output_type: Optional[str] = "latent", return_dict: bool = True,
                  control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guidance_rescale: float = 0.0,
                  callback=None, callback_steps: int = 1, original_size=None, crops_coords_top_left=(0, 0),
-                 target_size=None, **kwargs):
+                 target_size=None, denoising_end: Optional[float] = None, **kwargs):
         if eta not in (0, 0.0):
             raise NotImplementedError("eta != 0 (stochastic DDIM) is not supported: the device-resident step is the "
                                       "deterministic x' = cx*x + ce*eps update (the reference runs eta = 0)")
+        for k in ("negative_original_size", "negative_target_size", "prompt_2", "negative_prompt_2", "cross_attention_kwargs"):
+            if kwargs.get(k) is not None:
+                raise NotImplementedError(f"{k} is not supported on this path (custom_pipelines.py:23-56 accepts it for diffusers' sake)")
         height = height or self.default_sample_size * self.vae_scale_factor      # :189-190
         width = width or self.default_sample_size * self.vae_scale_factor
         if prompt_embeds is None:
@@ -101,7 +104,8 @@ class StableDiffusionXLCustomPipeline:
         eng.set_conditioning(prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
                              height, width, guidance_scale, guidance_rescale=guidance_rescale, original_size=original_size,
                              crops_coords_top_left=crops_coords_top_left, target_size=target_size)
-        eng.set_schedule(self.scheduler, num_inference_steps, control_guidance_start, control_guidance_end)
+        eng.set_schedule(self.scheduler, num_inference_steps, control_guidance_start, control_guidance_end,
+                         denoising_end=denoising_end)
         if latents is None:
             latents = randn_latents((S, 4, height // 8, width // 8), generator)       # prepare_latents :255-265
         out = eng.denoise(latents, callback=callback, callback_steps=callback_steps).clone()

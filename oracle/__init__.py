@@ -34,7 +34,12 @@ path (its only test asserts a tensor shape, ip_adapter/test_resampler.py:40).
 ``oracle.modules`` is pinned against the reference's OWN python modules imported
 verbatim from /root/reference (``oracle/refshim.py``); the generated vectors are
 committed under ``tests/golden/`` together with ``oracle/gen_golden.py``.
-``oracle.sdxl_unet`` and ``oracle.schedulers`` restate diffusers, which cannot be
-executed here: for those two pieces **parity is unpinned** beyond the parameter
-count / key-schema / structural checks (stated again in DESIGN.md).
+``oracle.pipeline`` (the denoise loop) is pinned against the reference's OWN
+``StableDiffusionXLCustomPipeline.__call__`` executed verbatim on a restated base
+class (``refshim.load_pipeline_class``, tests/test_oracle_loop_vs_reference.py).
+``oracle.sdxl_unet``, ``oracle.schedulers``, ``oracle.vae`` and
+``oracle.pipeline.rescale_noise_cfg`` restate diffusers, which cannot be executed
+here: for those pieces **parity is unpinned** beyond the parameter counts
+(UNet 2,567,463,684; VAE 83,653,863) / key-schema / closed-form checks (stated
+again in DESIGN.md).
 """

@@ -50,7 +50,7 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 def denoise(unet, scheduler, latents, prompt_embeds, negative_prompt_embeds, pooled, negative_pooled,
             height, width, num_inference_steps=30, guidance_scale=5.0,
             control_guidance_start=0.0, control_guidance_end=1.0, trace=None, guidance_rescale=0.0,
-            original_size=None, crops_coords_top_left=(0, 0), target_size=None):
+            original_size=None, crops_coords_top_left=(0, 0), target_size=None, denoising_end=None):
     """latents: [S,4,H/8,W/8] initial noise (already drawn on a CPU generator).
     prompt_embeds/negative_prompt_embeds: [S,77+T,2048]; pooled: [S,1280].
     Returns the final latents (output_type='latent')."""
@@ -68,6 +68,9 @@ def denoise(unet, scheduler, latents, prompt_embeds, negative_prompt_embeds, poo
     cond_scale = next(p.scale for p in unet.attn_processors.values()
                       if isinstance(p, IPAttnProcessor2_0))                    # :319-322
     ts = scheduler.timesteps
+    if denoising_end is not None and isinstance(denoising_end, float) and 0 < denoising_end < 1:      # :303-311
+        cutoff = int(round(1000 - denoising_end * 1000))                       # scheduler.config.num_train_timesteps
+        ts = ts[:len([t for t in ts if t >= cutoff])]
     for i, t in enumerate(ts):                                                 # :325
         if (i / len(ts) < control_guidance_start) or ((i + 1) / len(ts) > control_guidance_end):
             set_scale(unet, 0.0)                                               # :326-329

@@ -48,7 +48,7 @@ def load():
     """Returns a namespace with the reference classes: IPAttnProcessor2_0, AttnProcessor2_0,
     IPAttnProcessor (legacy), AttnProcessor (legacy), Cross_Attention, Resampler,
     HarmonyAttention, ImageProjModel."""
-    if _cache:
+    if "ns" in _cache:
         return _cache["ns"]
     if not available():
         raise RuntimeError("/root/reference is not present (refshim only works in the build container)")
@@ -101,3 +101,83 @@ def load():
         IPAdapterXL=ref_ipa.IPAdapterXL, IPAdapterPlusXL=ref_ipa.IPAdapterPlusXL)
     _cache["ns"] = ns
     return ns
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own denoise loop (ip_adapter/custom_pipelines.py:23-389), executed verbatim.
+# Its base class, diffusers' StableDiffusionXLPipeline, is absent; ``_PipeBase`` below supplies only the helpers the
+# loop calls (restated from diffusers 0.30.0: prepare_latents scales by init_noise_sigma, _get_add_time_ids
+# concatenates original_size + crops + target_size, prepare_extra_step_kwargs is empty for schedulers without
+# eta/generator, encode_prompt passes pre-computed embeddings through).  UNet and scheduler are injected objects.
+class _PipeBase:
+    vae_scale_factor = 8
+    text_encoder_2 = None
+
+    @property
+    def _execution_device(self):
+        return "cpu"
+
+    def check_inputs(self, *a, **k):
+        pass
+
+    def encode_prompt(self, prompt=None, prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+                      negative_pooled_prompt_embeds=None, **k):
+        return prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        assert latents is not None, "the parity tests always pass the initial noise"
+        return latents.to(dtype) * self.scheduler.init_noise_sigma
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        return {}
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype, text_encoder_projection_dim=None):
+        import torch
+        return torch.tensor([list(original_size) + list(crops_coords_top_left) + list(target_size)], dtype=dtype)
+
+    def progress_bar(self, total=None):
+        class _PB:
+            def __enter__(s):
+                return s
+
+            def __exit__(s, *a):
+                return False
+
+            def update(s):
+                pass
+        return _PB()
+
+    def maybe_free_model_hooks(self):
+        pass
+
+
+def load_pipeline_class():
+    """-> the reference's StableDiffusionXLCustomPipeline class (its __call__ body runs verbatim) on top of _PipeBase"""
+    if "pipe" in _cache:
+        return _cache["pipe"]
+    if not available():
+        raise RuntimeError("/root/reference is not present (refshim only works in the build container)")
+    from . import pipeline as opipe
+
+    class _Out:
+        def __init__(self, images=None):
+            self.images = images
+
+    saved = {k: sys.modules.get(k) for k in list(sys.modules)}
+    _stub("diffusers", StableDiffusionXLPipeline=_PipeBase)
+    _stub("diffusers.pipelines")
+    _stub("diffusers.pipelines.stable_diffusion_xl", StableDiffusionXLPipelineOutput=_Out)
+    _stub("diffusers.pipelines.stable_diffusion_xl.pipeline_stable_diffusion_xl", rescale_noise_cfg=opipe.rescale_noise_cfg)
+    pkg = types.ModuleType("_ref_ipa_pkg")
+    pkg.__path__ = [os.path.join(REF, "ip_adapter")]
+    sys.modules["_ref_ipa_pkg"] = pkg
+    try:
+        _load_file("_ref_ipa_pkg.utils", os.path.join(REF, "ip_adapter", "utils.py"))
+        ap = _load_file("_ref_ipa_pkg.attention_processor", os.path.join(REF, "ip_adapter", "attention_processor.py"))
+        cp = _load_file("_ref_ipa_pkg.custom_pipelines", os.path.join(REF, "ip_adapter", "custom_pipelines.py"))
+    finally:
+        for k in list(sys.modules):
+            if k not in saved and (k.split(".")[0] == "diffusers"):
+                sys.modules.pop(k, None)
+    _cache["pipe"] = (cp.StableDiffusionXLCustomPipeline, ap)
+    return _cache["pipe"]

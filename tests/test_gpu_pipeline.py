@@ -69,6 +69,16 @@ def test_denoise_non_square_ragged_token_count():
              height=384, width=320, num_inference_steps=1, guidance_scale=5.0, latents=det_randn((1, 4, 48, 40), 3))
 
 
+def test_denoise_denoising_end_truncates_like_reference():
+    """denoising_end (custom_pipelines.py:303-311): the loop stops below the cut-off timestep and the IP-scale gating
+    window counts the truncated list; the oracle loop for this case is pinned to the reference's own loop on CPU
+    (tests/test_oracle_loop_vs_reference.py)"""
+    out, ref = denoise_pair(DEV, torch.bfloat16, steps=5, denoising_end=0.6, cg_end=0.7)
+    assert rel_rms(out, ref) < 3e-2
+    full, _ = denoise_pair(DEV, torch.bfloat16, steps=5, cg_end=0.7)
+    assert rel_rms(out, full) > 1e-2
+
+
 def test_denoise_is_deterministic_and_replayable():
     a, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
     b, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
