@@ -200,7 +200,8 @@ class IPAdapterXL(IPAdapter):
         """Same arguments as the reference; additionally ``clip_image_embeds`` / ``prompt_embeds`` (a 4-tuple as
         returned by encode_prompt) / ``extra_prompt_embeds`` may be given when no encoders are attached."""
         self.set_scale(scale)
-        kwargs.pop("number_class_crossattention", None)        # stray kwarg of test.py:38 (swallowed upstream)
+        # a stray number_class_crossattention= (test.py:38) travels on to the pipeline inside **kwargs, as upstream;
+        # StableDiffusionXLCustomPipeline.__call__ here ignores unknown keywords like diffusers' stock pipeline does
         n = 1 if not isinstance(pil_image, (list, tuple)) else len(pil_image)
         prompt = prompt if prompt is not None else "best quality, high quality"
         negative_prompt = negative_prompt if negative_prompt is not None else \

@@ -1,0 +1,124 @@
+"""CPU, build container only: the host orchestration of ``IPAdapterXL`` (rows a8-a10 of SURVEY.md section 8) against
+the reference's OWN ``IPAdapterXL`` class (ip_adapter/ip_adapter.py:249-340, imported verbatim through
+oracle/refshim.py): which processors ``set_ip_adapter`` installs where, ``get_image_embeds`` (HarmonyAttention fused
+into the CLIP embedding, zero-image uncond branch), and what ``generate`` hands to the pipeline (tiling, text || image
+token order, pooled embeddings, seed -> generator, kwargs pass-through, scale).  Both adapters get the same fake
+pipeline / CLIP objects and the same seeded projection modules (the oracle's, which are pinned to the reference's);
+nothing here needs a GPU because the HIP modules are swapped for those CPU modules before any compute."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import modules as om
+from oracle import refshim
+from oracle.detfill import det_fill, det_randn
+from oracle.sdxl_unet import UNet2DConditionModel as OracleUNet
+from oracle.sdxl_unet import tiny_config
+
+pytestmark = pytest.mark.skipif(not refshim.available(), reason="reference tree not present")
+HALF = torch.float16
+
+
+class _Pipe:
+    def __init__(self, unet):
+        self.unet, self.calls, self.encoded = unet, [], []
+
+    def to(self, device):
+        return self
+
+    def encode_prompt(self, prompt, num_images_per_prompt=1, do_classifier_free_guidance=True, negative_prompt=None, **kw):
+        self.encoded.append((tuple(prompt) if isinstance(prompt, list) else prompt, num_images_per_prompt,
+                             tuple(negative_prompt) if isinstance(negative_prompt, list) else negative_prompt))
+        n = (len(prompt) if isinstance(prompt, list) else 1) * num_images_per_prompt
+        seed = sum(map(ord, "".join(prompt) if isinstance(prompt, list) else prompt)) % 997
+        cd = self.unet.config.cross_attention_dim
+        return (det_randn((n, 77, cd), seed).to(HALF), det_randn((n, 77, cd), seed + 1).to(HALF),
+                det_randn((n, 32), seed + 2).to(HALF), det_randn((n, 32), seed + 3).to(HALF))
+
+    def __call__(self, **kw):
+        self.calls.append(kw)
+        return type("O", (), {"images": ["img"] * kw["prompt_embeds"].shape[0]})()
+
+
+class _Proc:                      # CLIPImageProcessor stand-in
+    def __call__(self, images=None, return_tensors=None):
+        arr = np.stack([np.asarray(im, dtype=np.float32).mean(axis=(0, 1)) for im in images])
+        return type("B", (), {"pixel_values": torch.from_numpy(arr)})()
+
+
+class _Clip(torch.nn.Module):     # CLIPVisionModelWithProjection stand-in: pixel statistics -> [B, 128]
+    config = type("C", (), {"projection_dim": 128, "hidden_size": 64})()
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(det_randn((3, 128), 77), requires_grad=False)
+
+    def forward(self, px, output_hidden_states=False):
+        return type("O", (), {"image_embeds": ((px.float() / 255.0) @ self.w.float()).to(px.dtype)})()   # an fp16 model returns fp16
+
+
+def _modules(mod_ns):
+    """the projection + HarmonyAttention modules with identical seeded weights, as classes of `mod_ns`"""
+    proj = det_fill(mod_ns.ImageProjModel(cross_attention_dim=256, clip_embeddings_dim=128, clip_extra_context_tokens=4), 5)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ha = mod_ns.HarmonyAttention(image_hidden_size=128, text_context_dim=256, inter_dim=512, cross_heads=8,
+                                     reshape_blocks=8, cross_value_dim=64, scale=1.0, fusion_method="cross_attention")
+    return proj.to(HALF), det_fill(ha, 3).to(HALF)
+
+
+def test_ipadapterxl_orchestration_matches_reference():
+    import contextlib, io
+    ref = refshim.load()
+    img = Image.fromarray((np.random.RandomState(0).rand(24, 20, 3) * 255).astype("uint8"))
+    kwargs = dict(prompt="lions", negative_prompt="blurry", extra_text="eight sheep", scale=0.6, num_samples=1, seed=42,
+                  num_inference_steps=7, guidance_scale=5.0, height=256, width=256)
+
+    # ---- the reference adapter (constructed without __init__: it would download CLIP weights) ----
+    r_unet = det_fill(OracleUNet(tiny_config()), 5)
+    r = ref.IPAdapterXL.__new__(ref.IPAdapterXL)
+    r.device, r.num_tokens, r.pipe = "cpu", 4, _Pipe(r_unet)
+    r.image_encoder, r.clip_image_processor = _Clip(), _Proc()
+    r.image_proj_model, r.number_class_crossattention = _modules(ref)
+    r.set_ip_adapter()                                                            # ip_adapter.py:99-125, verbatim
+    with contextlib.redirect_stdout(io.StringIO()):                               # HarmonyAttention prints upstream
+        out_r = r.generate(img, number_class_crossattention=r.number_class_crossattention, **kwargs)
+
+    # ---- ours, same fake objects; HIP modules swapped for the (pinned) oracle modules before any compute ----
+    from imagharmony_amd.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+    from imagharmony_amd.ip_adapter import IPAdapterXL
+    m_unet = det_fill(OracleUNet(tiny_config()), 5)
+    m = IPAdapterXL(_Pipe(m_unet), None, None, "cpu", num_tokens=4, inference=True, dtype=HALF,
+                    image_encoder=_Clip(), clip_image_processor=_Proc())
+    assert m.clip_embeddings_dim == 128
+    m.image_proj_model, m.number_class_crossattention = _modules(om)
+    out_m = m.generate(pil_image=img, number_class_crossattention=m.number_class_crossattention, **kwargs)
+
+    # set_ip_adapter: same processor kinds / shapes / skip flags under the same names
+    rp, mp = r_unet.attn_processors, m_unet.attn_processors
+    assert list(rp) == list(mp) and len(rp) > 0
+    for k in rp:
+        if type(rp[k]).__name__ == "AttnProcessor2_0":      # (the adapter module imports its own copy of the class)
+            assert isinstance(mp[k], AttnProcessor2_0), k
+        else:
+            assert type(rp[k]).__name__ == "IPAttnProcessor2_0" and isinstance(mp[k], IPAttnProcessor2_0), k
+            assert (mp[k].hidden_size, mp[k].cross_attention_dim, mp[k].num_tokens, mp[k].skip) == \
+                   (rp[k].hidden_size, rp[k].cross_attention_dim, rp[k].num_tokens, rp[k].skip), k
+            assert mp[k].to_k_ip.weight.shape == rp[k].to_k_ip.weight.shape
+            assert mp[k].scale == rp[k].scale == 0.6                              # generate() -> set_scale
+    # generate: identical encode_prompt calls and identical pipeline arguments
+    assert r.pipe.encoded == m.pipe.encoded
+    kr, km = r.pipe.calls[-1], m.pipe.calls[-1]
+    assert out_r == out_m == ["img"]
+    assert set(kr) == set(km)
+    for k in kr:
+        if torch.is_tensor(kr[k]):
+            assert kr[k].shape == km[k].shape and torch.allclose(kr[k].float(), km[k].float(), atol=2e-3, rtol=2e-3), k
+        elif k == "number_class_crossattention":                            # test.py:38's stray kwarg travels through both
+            assert kr[k] is r.number_class_crossattention and km[k] is m.number_class_crossattention
+        elif isinstance(kr[k], torch.Generator):
+            assert kr[k].initial_seed() == km[k].initial_seed() == 42
+        else:
+            assert kr[k] == km[k], k
+    assert kr["prompt_embeds"].shape == (1, 77 + 4, 256)
