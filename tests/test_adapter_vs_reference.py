@@ -122,3 +122,50 @@ def test_ipadapterxl_orchestration_matches_reference():
         else:
             assert kr[k] == km[k], k
     assert kr["prompt_embeds"].shape == (1, 77 + 4, 256)
+
+
+class _ClipH(torch.nn.Module):    # vision model with hidden states: the PlusXL path reads hidden_states[-2]
+    config = type("C", (), {"projection_dim": 128, "hidden_size": 64})()
+
+    def forward(self, px, output_hidden_states=False):
+        base = (px.float() / 255.0).unsqueeze(1).repeat(1, 9, 1)                   # [B, 9 tokens, 3]
+        w = det_randn((3, 64), 78)
+        hs = [(base * (i + 1)) @ w for i in range(3)]
+        return type("O", (), {"hidden_states": [h.to(px.dtype) for h in hs]})()
+
+
+def test_ipadapterplusxl_orchestration_matches_reference():
+    """IPAdapterPlusXL (ip_adapter.py:389-478): Resampler over the penultimate hidden states of the image and of a
+    zero image, then the same hand-over to the pipeline; multi-sample tiling (num_samples = 2)"""
+    ref = refshim.load()
+    img = Image.fromarray((np.random.RandomState(1).rand(24, 20, 3) * 255).astype("uint8"))
+    cfg = dict(dim=128, depth=2, dim_head=32, heads=4, num_queries=16, embedding_dim=64, output_dim=256, ff_mult=2)
+    kwargs = dict(prompt=None, negative_prompt=None, scale=0.9, num_samples=2, seed=7, num_inference_steps=5, guidance_scale=4.0)
+
+    r = ref.IPAdapterPlusXL.__new__(ref.IPAdapterPlusXL)
+    r.device, r.num_tokens, r.pipe = "cpu", 16, _Pipe(det_fill(OracleUNet(tiny_config()), 5))
+    r.image_encoder, r.clip_image_processor = _ClipH(), _Proc()
+    r.image_proj_model = det_fill(ref.Resampler(**cfg), 9).to(HALF)
+    r.set_ip_adapter()
+    out_r = r.generate(img, **kwargs)
+
+    from imagharmony_amd.ip_adapter import IPAdapterPlusXL
+    m = IPAdapterPlusXL(_Pipe(det_fill(OracleUNet(tiny_config()), 5)), None, None, "cpu", num_tokens=16, dtype=HALF,
+                        image_encoder=_ClipH(), clip_image_processor=_Proc())
+    assert m.clip_hidden_size == 64
+    m.image_proj_model = det_fill(om.Resampler(**cfg), 9).to(HALF)
+    out_m = m.generate(pil_image=img, **kwargs)
+
+    assert out_r == out_m == ["img", "img"] and r.pipe.encoded == m.pipe.encoded
+    assert r.pipe.encoded[0][0] == ("best quality, high quality",)                 # default prompts (ip_adapter.py:433-436)
+    kr, km = r.pipe.calls[-1], m.pipe.calls[-1]
+    assert set(kr) == set(km)
+    for k in kr:
+        if torch.is_tensor(kr[k]):
+            assert kr[k].shape == km[k].shape and torch.allclose(kr[k].float(), km[k].float(), atol=3e-3, rtol=3e-3), k
+        elif isinstance(kr[k], torch.Generator):
+            assert kr[k].initial_seed() == km[k].initial_seed() == 7
+        else:
+            assert kr[k] == km[k], k
+    assert kr["prompt_embeds"].shape == (2, 77 + 16, 256)
+    assert all(p.scale == 0.9 for p in m.pipe.unet.attn_processors.values() if hasattr(p, "to_k_ip"))
