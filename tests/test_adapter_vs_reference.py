@@ -169,3 +169,56 @@ def test_ipadapterplusxl_orchestration_matches_reference():
             assert kr[k] == km[k], k
     assert kr["prompt_embeds"].shape == (2, 77 + 16, 256)
     assert all(p.scale == 0.9 for p in m.pipe.unet.attn_processors.values() if hasattr(p, "to_k_ip"))
+
+
+def test_get_generator_and_checkpoint_loading_match_reference(tmp_path):
+    """get_generator (ip_adapter/utils.py:83-93) and load_ip_adapter of an ip_adapter.bin (ip_adapter.py:135-154): both
+    adapters end up with the same weights in the projection, the HarmonyAttention module and the 70 -> (here 22)
+    IP processors, keyed '<idx>.to_k_ip.weight' in attn_processors order"""
+    import contextlib, io
+    ref = refshim.load()
+    from imagharmony_amd.utils import get_generator
+    for seed in (None, 5, [1, 2, 3]):
+        a, b = ref.get_generator(seed, "cpu"), get_generator(seed, "cpu")
+        if seed is None:
+            assert a is None and b is None
+        elif isinstance(seed, list):
+            assert [g.initial_seed() for g in a] == [g.initial_seed() for g in b] == seed
+        else:
+            assert a.initial_seed() == b.initial_seed() == seed and torch.equal(torch.randn(4, generator=a), torch.randn(4, generator=b))
+
+    # a checkpoint in the reference's own format, written from a donor reference adapter
+    donor_unet = det_fill(OracleUNet(tiny_config()), 5)
+    donor = ref.IPAdapterXL.__new__(ref.IPAdapterXL)
+    donor.device, donor.num_tokens, donor.pipe = "cpu", 4, _Pipe(donor_unet)
+    donor.set_ip_adapter()
+    for n, p in donor_unet.attn_processors.items():
+        det_fill(p, 21, prefix=n)
+    proj, ha = _modules(ref)
+    layers = torch.nn.ModuleList(donor_unet.attn_processors.values())
+    path = str(tmp_path / "ip_adapter.bin")
+    torch.save({"image_proj": det_fill(proj, 31).state_dict(), "ip_adapter": layers.state_dict(),
+                "composed_adapter": det_fill(ha, 33).state_dict()}, path)
+    assert sorted(layers.state_dict())[0].endswith(".to_k_ip.weight") and len(layers.state_dict()) == 2 * sum(
+        hasattr(p, "to_k_ip") for p in donor_unet.attn_processors.values())
+
+    r = ref.IPAdapterXL.__new__(ref.IPAdapterXL)
+    r.device, r.num_tokens, r.pipe, r.ip_ckpt = "cpu", 4, _Pipe(det_fill(OracleUNet(tiny_config()), 5)), path
+    r.image_proj_model, r.number_class_crossattention = _modules(ref)
+    r.set_ip_adapter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        r.load_ip_adapter()
+
+    from imagharmony_amd.ip_adapter import IPAdapterXL
+    from imagharmony_amd.modules import HarmonyAttention
+    hm = HarmonyAttention(image_hidden_size=128, text_context_dim=256, inter_dim=512, cross_heads=8, reshape_blocks=8,
+                          cross_value_dim=64, scale=1.0, fusion_method="cross_attention")
+    m = IPAdapterXL(_Pipe(det_fill(OracleUNet(tiny_config()), 5)), None, path, "cpu", num_tokens=4, inference=True,
+                    number_class_crossattention=hm, dtype=HALF, clip_embeddings_dim=128)      # loads in __init__ (ip_adapter.py:89)
+    for (kr_, vr), (km_, vm) in zip(r.image_proj_model.state_dict().items(), m.image_proj_model.state_dict().items()):
+        assert kr_ == km_ and torch.equal(vr.float(), vm.float())
+    for (kr_, vr), (km_, vm) in zip(r.number_class_crossattention.state_dict().items(), m.number_class_crossattention.state_dict().items()):
+        assert kr_ == km_ and torch.equal(vr.float(), vm.float())
+    rl = torch.nn.ModuleList(r.pipe.unet.attn_processors.values()).state_dict()
+    ml = torch.nn.ModuleList(m.pipe.unet.attn_processors.values()).state_dict()
+    assert list(rl) == list(ml) and all(torch.equal(rl[k].float(), ml[k].float()) for k in rl)
