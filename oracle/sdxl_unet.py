@@ -112,8 +112,24 @@ class Attention(nn.Module):
             self._modules.pop("processor")
         self.processor = p
 
-    def prepare_attention_mask(self, *a, **k):
+    def prepare_attention_mask(self, attention_mask=None, *a, **k):
+        if attention_mask is None:
+            return None
         raise NotImplementedError("attention masks are not used on the SDXL path")
+
+    # the three helpers only the reference's legacy (torch < 2) processors call
+    # (ip_adapter/attention_processor.py:111-119,205-224); diffusers 0.30.0 semantics with upcast_* off
+    def head_to_batch_dim(self, t):
+        b, l, c = t.shape
+        return t.reshape(b, l, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, l, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, l, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, l, d).permute(0, 2, 1, 3).reshape(bh // self.heads, l, d * self.heads)
+
+    def get_attention_scores(self, query, key, attention_mask=None):
+        assert attention_mask is None
+        return torch.softmax(torch.bmm(query, key.transpose(-1, -2)) * self.scale, dim=-1)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,

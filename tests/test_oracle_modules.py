@@ -102,3 +102,22 @@ def test_oracle_state_dicts_interchange_with_reference_live():
         assert rel_rms(pairs[0][1](text, img), pairs[0][0](text, img)) < TOL
         x = det_randn((2, 257, 1280), 3)
         assert rel_rms(pairs[2][1](x), pairs[2][0](x)) < TOL
+
+
+@pytest.mark.skipif(not refshim.available(), reason="/root/reference not present")
+@pytest.mark.parametrize("case", ["c1280_t4", "c128_t32"])
+def test_reference_legacy_processors_equal_the_2_0_golden(case):
+    """the reference's torch<2 processors (attention_processor.py:60-241, baddbmm + softmax + bmm) against the golden
+    outputs of its 2_0 processors: same math -- which is why the legacy names alias the 2_0 classes here, as
+    ip_adapter.py:13-24 does upstream on torch >= 2.  Their attn_map is the true probability tensor (:221-222)."""
+    ref = refshim.load()
+    g = torch.load(os.path.join(GOLDEN, f"attn_{case}.pt"))
+    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    hs, ehs = attn_inputs(case)
+    with torch.no_grad():
+        attn = make_attn(case, cross=True)
+        p = det_fill(ref.IPAttnProcessor(c, cd, scale=scale, num_tokens=t), 17, prefix="proc.")
+        y = p(attn, hs, encoder_hidden_states=ehs)
+        assert rel_rms(y, g["ip_skip0"]) < 1e-5
+        assert p.attn_map.shape[-1] == t and torch.allclose(p.attn_map.sum(-1), torch.ones_like(p.attn_map.sum(-1)), atol=1e-5)
+        assert rel_rms(ref.AttnProcessor()(make_attn(case, cross=False), hs), g["self"]) < 1e-5
