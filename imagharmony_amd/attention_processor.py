@@ -83,6 +83,12 @@ def _check_attn(attn, hidden_states, attention_mask):
         raise NotImplementedError("spatial_norm / group_norm / norm_cross are dead branches for SDXL")
     if hidden_states.ndim != 3:
         raise NotImplementedError("4-D hidden states are a dead branch for SDXL (attention_processor.py:379-381)")
+    inner = attn.to_q.weight.shape[0]
+    if inner != attn.heads * HEAD_DIM or abs(float(getattr(attn, "scale", HEAD_DIM ** -0.5)) - HEAD_DIM ** -0.5) > 1e-6:
+        # the kernels index heads as h*64 and fold scale = 1/8 into the exponent: any other head width (SD-1.x:
+        # 40 / 80 / 160) would silently use the wrong scale and read past the head -- refuse instead
+        raise NotImplementedError(f"head_dim {inner // max(attn.heads, 1)} (scale {getattr(attn, 'scale', None)}): the HIP "
+                                  f"attention kernels are built for head_dim {HEAD_DIM} (SDXL) only")
 
 
 class KVCache:

@@ -17,7 +17,18 @@ _DT = {torch.bfloat16: L.IMH_DT_BF16, torch.float16: L.IMH_DT_F16}
 _TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning.json")
 
 
+_TUNING_CACHE = None
+
+
 def _load_tuning():
+    """parsed once per process (every eager processor call builds a Ctx)"""
+    global _TUNING_CACHE
+    if _TUNING_CACHE is None:
+        _TUNING_CACHE = _read_tuning()
+    return _TUNING_CACHE
+
+
+def _read_tuning():
     try:
         with open(_TUNING_PATH) as f:
             raw = json.load(f)
@@ -43,7 +54,7 @@ class Ctx:
         self.plan = self.lib.imh_plan_create() if record else None
         self.keep = []          # tensors referenced by recorded ops
         self.tag = 0
-        self.tags = []          # per recorded op: (tag, kind, descr, flops, bytes)
+        self.tags = []          # per recorded op: (tag, kind, descr, flops, bytes, shape, epilogue/config dict)
         self._pool = {}
         self._bases = {}        # storage ptr -> pool-owned base tensor
         self._live = set()
@@ -103,13 +114,13 @@ class Ctx:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ emit
-    def _emit(self, kind, args, ew_op=0, descr="", flops=0.0, nbytes=0.0, keep=(), shape=None):
+    def _emit(self, kind, args, ew_op=0, descr="", flops=0.0, nbytes=0.0, keep=(), shape=None, epi=None):
         if self.record:
             rc = self.lib.imh_plan_add(self.plan, kind, C.byref(args), ew_op, self.tag)
             if rc < 0:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(k for k in keep if k is not None)
-            self.tags.append((self.tag, kind, descr, flops, nbytes, shape))
+            self.tags.append((self.tag, kind, descr, flops, nbytes, shape, epi))
             self._ops.append((kind, args, self._cold(keep) if kind == L.OP_GEMM else []))
             return
         s = self.stream()
@@ -192,7 +203,9 @@ class Ctx:
         if _args_only:
             return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + tuple(ln or ())
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual, part) + tuple(ln or ()), shape=(M, N, K, 0, None))
+                   keep=(x, w, out, bias, rowadd, residual, part) + tuple(ln or ()), shape=(M, N, K, 0, None),
+                   epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
+                            rows_per_batch=rows_per_batch, cfg=(bm, bn, sp)))
         return (out, part) if rowstats else out
 
     def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
@@ -205,7 +218,8 @@ class Ctx:
             if rc < 0:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(t for t in k1 + k2 if t is not None)
-            self.tags.append((self.tag, L.OP_GEMM, descr, f1 + f2, b1 + b2, None))
+            self.tags.append((self.tag, L.OP_GEMM, descr, f1 + f2, b1 + b2, None,
+                              dict(dual=((a1.M, a1.N, a1.K, a1.flags), (a2.M, a2.N, a2.K, a2.flags)), cfg=tuple(cfg))))
             self._ops.append((L.OP_GEMM_DUAL, pair, self._cold(k1[:2] + k2[:2])))
         else:
             L.check(self.lib.imh_gemm_dual(C.byref(pair[0]), C.byref(pair[1]), self.stream()), descr)
@@ -240,7 +254,9 @@ class Ctx:
         es = x.element_size()
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K,
                    nbytes=es * (B * H * W * Cin + N * K + M * N), keep=(x, w, out, bias, rowadd, residual),
-                   shape=(M, N, K, 1, (B, H, W, Cin, stride, up)))
+                   shape=(M, N, K, 1, (B, H, W, Cin, stride, up)),
+                   epi=dict(flags=0, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
+                            rows_per_batch=Ho * Wo, cfg=(bm, bn, sp)))
         return out
 
     # ------------------------------------------------------------------ attention

@@ -82,10 +82,19 @@ class StableDiffusionXLCustomPipeline:
                  negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0,
                  generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None, latents=None,
                  prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
-                 negative_pooled_prompt_embeds=None, output_type: Optional[str] = "latent", return_dict: bool = True,
+                 negative_pooled_prompt_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
                  control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guidance_rescale: float = 0.0,
                  callback=None, callback_steps: int = 1, original_size=None, crops_coords_top_left=(0, 0),
                  target_size=None, denoising_end: Optional[float] = None, **kwargs):
+        """``output_type`` defaults to "pil" as the reference does (custom_pipelines.py:42), so ``test.py:43``'s
+        ``images[0].save(...)`` works; that needs a VAE (``vae=`` / ``vae_decode=``) -- without one the call fails
+        BEFORE denoising with a clear error (pass output_type="latent" for latents).  The default scheduler is
+        DDIM (BASELINE.json's metric; IP-Adapter convention) -- stock SDXL ships EulerDiscrete: pass
+        ``scheduler=EulerDiscreteScheduler()`` for that."""
+        if output_type != "latent" and self.vae is None and self.vae_decode is None:
+            raise NotImplementedError("output_type=%r needs a VAE: construct the pipeline with "
+                                      "vae=imagharmony_amd.vae.AutoencoderKL(...) or vae_decode=callable, or pass "
+                                      "output_type='latent'" % (output_type,))
         if eta not in (0, 0.0):
             raise NotImplementedError("eta != 0 (stochastic DDIM) is not supported: the device-resident step is the "
                                       "deterministic x' = cx*x + ce*eps update (the reference runs eta = 0)")
@@ -116,9 +125,6 @@ class StableDiffusionXLCustomPipeline:
                 if self.watermark is not None:
                     image = self.watermark.apply_watermark(image)
                 out = postprocess(image, output_type)
-            elif self.vae_decode is not None:
-                out = self.vae_decode(out)
             else:
-                raise NotImplementedError("no VAE attached: use output_type='latent', or construct the pipeline with "
-                                          "vae=imagharmony_amd.vae.AutoencoderKL(...) or vae_decode=callable")
+                out = self.vae_decode(out)
         return StableDiffusionXLPipelineOutput(images=out) if return_dict else (out,)

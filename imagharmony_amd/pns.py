@@ -11,8 +11,11 @@ per-step communication:
     (and optionally of the weights, to guarantee identical replicas), the all_gather of N fp32 scores and
     the broadcast of the winning latent from its owner.
 
-The judge is unpinned upstream (a VLM); ``scorer`` is pluggable and the default is a deterministic
-latent-space statistic so that runs are reproducible.  It is NOT a quality claim.
+The judge is unpinned upstream (a VLM, no code); ``scorer`` is pluggable.  ``ClipPreferenceJudge`` is the
+deterministic default of SURVEY.md 8f-2: decode the preview, embed it with the CLIP vision model the adapter
+already holds, score = cosine similarity to the harmony-fused image embedding the denoise was conditioned on.
+``default_scorer`` (a latent statistic) is the fallback when no VAE / CLIP model is attached.  Neither is a
+quality claim; both are off the timed path of bench.py.
 """
 from typing import Callable, List, Optional, Sequence
 
@@ -36,20 +39,113 @@ def seed_latents(seed: int, shape) -> torch.Tensor:
     return torch.randn(tuple(shape), generator=torch.Generator("cpu").manual_seed(int(seed)), dtype=torch.float32)
 
 
-def broadcast_module_(module: torch.nn.Module, src: int = 0):
-    """one-time weight broadcast so every rank holds the same replica (RCCL over xGMI on GPUs)"""
+def broadcast_module_(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 512 << 20):
+    """one-time weight broadcast so every rank holds the same replica (RCCL over xGMI on GPUs).  The ~1700 parameter
+    tensors of the UNet travel as a few flat buckets per dtype (xGMI is point-to-point: a handful of large ring
+    broadcasts, not thousands of latency-bound small ones).  Returns the number of collectives issued."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src)
-    for b in module.buffers():
-        dist.broadcast(b.data, src=src)
+        return 0
+    rank = dist.get_rank()
+    groups = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel():
+            groups.setdefault((t.dtype, t.device), []).append(t.data)
+    n_coll = 0
+    for (dtype, device), tensors in groups.items():
+        bucket, size = [], 0
+        esz = tensors[0].element_size()
+
+        def flush():
+            nonlocal bucket, size, n_coll
+            if not bucket:
+                return
+            flat = torch.empty(size, dtype=dtype, device=device)
+            off = 0
+            if rank == src:
+                for t in bucket:
+                    flat[off:off + t.numel()].copy_(t.reshape(-1))
+                    off += t.numel()
+            dist.broadcast(flat, src=src)
+            n_coll += 1
+            if rank != src:
+                off = 0
+                for t in bucket:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+            bucket, size = [], 0
+
+        for t in tensors:
+            if size and (size + t.numel()) * esz > bucket_bytes:
+                flush()
+            bucket.append(t)
+            size += t.numel()
+        flush()
+    return n_coll
 
 
 def broadcast_tensors_(tensors: Sequence[torch.Tensor], src: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for t in tensors:
             dist.broadcast(t, src=src)
+
+
+class ClipPreferenceJudge:
+    """Default PNS judge (README.md:27 / assets/1.png name a VLM judge, no code): a candidate's
+    preview latents are decoded (``decode_fn``: latents [S,4,h,w] -> images [S,3,H,W] in [-1,1], e.g.
+    ``lambda z: decode_latents(vae, z)``), resized / normalised like CLIPImageProcessor does (bicubic to
+    ``image_size``, centre crop, CLIP mean / std -- as tensor ops, so the score is reproducible bit for bit on one
+    backend), embedded by the CLIP vision model (stock transformers module, the step before the path, 8f-4), and
+    scored by cosine similarity with ``target_embeds`` -- the harmony-fused image embedding
+    ``clip + HarmonyAttention(text, clip)`` (ip_adapter.py:170-173) the denoise was conditioned on."""
+
+    MEAN = (0.48145466, 0.4578275, 0.40821073)
+    STD = (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, decode_fn, image_encoder, target_embeds, image_size=None):
+        self.decode_fn = decode_fn
+        self.image_encoder = image_encoder
+        cfg = getattr(image_encoder, "config", None)
+        self.image_size = int(image_size or getattr(cfg, "image_size", 224))
+        t = target_embeds.detach().float().reshape(-1, target_embeds.shape[-1])
+        self.target = torch.nn.functional.normalize(t.mean(0, keepdim=True), dim=-1)
+
+    @torch.no_grad()
+    def preprocess(self, images):
+        x = (images.float() / 2 + 0.5).clamp(0, 1)
+        H, W = x.shape[-2:]
+        sz = self.image_size
+        sc = sz / min(H, W)                                   # shortest edge -> sz, then centre crop (CLIPImageProcessor)
+        nh, nw = max(sz, round(H * sc)), max(sz, round(W * sc))
+        x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False, antialias=True).clamp(0, 1)
+        t, l = (nh - sz) // 2, (nw - sz) // 2
+        x = x[..., t:t + sz, l:l + sz]
+        mean = torch.tensor(self.MEAN, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(self.STD, device=x.device).view(1, 3, 1, 1)
+        return (x - mean) / std
+
+    @torch.no_grad()
+    def __call__(self, latents):
+        images = self.decode_fn(latents)
+        p = next(self.image_encoder.parameters())
+        px = self.preprocess(images).to(device=p.device, dtype=p.dtype)
+        emb = self.image_encoder(px).image_embeds.float()
+        emb = torch.nn.functional.normalize(emb, dim=-1)
+        return (emb * self.target.to(emb.device)).sum(-1)
+
+
+def two_stage_fns(engine, scheduler, preview_steps=10, final_steps=30, **schedule_kw):
+    """The two-stage schedule of assets/1.png on a ``DenoiseEngine`` whose conditioning is set: every candidate seed
+    gets a ``preview_steps`` denoise ("+10 steps"), the judged-best noise the full ``final_steps`` one ("+30 steps").
+    Returns (preview_fn, final_fn) for ``run_pns``."""
+    def preview(noise):
+        engine.set_schedule(scheduler, preview_steps, **schedule_kw)
+        return engine.denoise(noise).clone()
+
+    def final(noise):
+        engine.set_schedule(scheduler, final_steps, **schedule_kw)
+        return engine.denoise(noise).clone()
+
+    return preview, final
 
 
 def run_pns(denoise_fn: Callable[[torch.Tensor], torch.Tensor], seeds: Sequence[int], latent_shape,

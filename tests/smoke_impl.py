@@ -55,7 +55,7 @@ def denoise_pair(device, dtype, steps=2, hw=32, guidance=5.0, scheduler="ddim", 
                                            device=device, dtype=dtype, use_graph=use_graph)
     out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
                height=hw * 8, width=hw * 8, num_inference_steps=steps, guidance_scale=guidance, latents=lat,
-               control_guidance_end=cg_end, **extra).images
+               control_guidance_end=cg_end, output_type="latent", **extra).images
     return out.float().cpu(), ref
 
 

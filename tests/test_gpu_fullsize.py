@@ -28,7 +28,8 @@ def sdxl():
 def run(pipe, pe, ne, po, no, guidance=5.0, steps=2, seed=3):
     z = torch.randn(1, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(seed))
     return pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
-                height=1024, width=1024, num_inference_steps=steps, guidance_scale=guidance, latents=z).images.clone()
+                height=1024, width=1024, num_inference_steps=steps, guidance_scale=guidance, latents=z,
+                output_type="latent").images.clone()
 
 
 def test_fullsize_properties(sdxl):
@@ -107,7 +108,7 @@ def test_fullsize_stacked_candidates_configs_3_and_4(dtype, S, T, sched):
     pe, ne, po, no = [t.to(DEV) for t in bench.synthetic_conditioning(T)]
     z = torch.randn(S, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(11))
     z[3] = z[0]                                                                     # candidate 3 == candidate 0
-    kw = dict(height=1024, width=1024, num_inference_steps=2, guidance_scale=5.0)
+    kw = dict(height=1024, width=1024, num_inference_steps=2, guidance_scale=5.0, output_type="latent")
     stacked = pipe(prompt_embeds=pe.repeat(S, 1, 1), negative_prompt_embeds=ne.repeat(S, 1, 1),
                    pooled_prompt_embeds=po.repeat(S, 1), negative_pooled_prompt_embeds=no.repeat(S, 1), latents=z, **kw).images.clone()
     assert stacked.shape == (S, 4, 128, 128) and torch.isfinite(stacked).all()

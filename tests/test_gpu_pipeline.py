@@ -61,12 +61,13 @@ def test_denoise_non_square_ragged_token_count():
     ref = oracle_denoise(ou, OracleDDIM(), lat, pe, ne, po, no, 256, 320, num_inference_steps=2, guidance_scale=5.0)
     pipe = StableDiffusionXLCustomPipeline(hu, scheduler=hs.DDIMScheduler(), device=DEV, dtype=dtype)
     out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
-               height=256, width=320, num_inference_steps=2, guidance_scale=5.0, latents=lat).images
+               height=256, width=320, num_inference_steps=2, guidance_scale=5.0, latents=lat, output_type="latent").images
     assert out.shape == (1, 4, 32, 40)
     assert rel_rms(out.float().cpu(), ref) < 3e-2
     with pytest.raises(Exception, match="multiple of 16"):          # 8x... tokens not a multiple of 16: a clear error, not garbage
         pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=po, negative_pooled_prompt_embeds=no,
-             height=384, width=320, num_inference_steps=1, guidance_scale=5.0, latents=det_randn((1, 4, 48, 40), 3))
+             height=384, width=320, num_inference_steps=1, guidance_scale=5.0, latents=det_randn((1, 4, 48, 40), 3),
+             output_type="latent")
 
 
 def test_denoise_denoising_end_truncates_like_reference():
@@ -131,7 +132,7 @@ def test_ipadapterxl_generate_call_sequence():
               det_randn((1, ocfg.pooled_dim), 4))
     kw = dict(clip_image_embeds=det_randn((1, 128), 5), prompt_embeds=embeds, extra_prompt_embeds=det_randn((1, 77, cd), 6),
               num_samples=1, num_inference_steps=2, guidance_scale=5.0, height=256, width=256,
-              number_class_crossattention=ha)
+              number_class_crossattention=ha, output_type="latent")
     a = ip.generate(seed=42, scale=1.0, **kw)
     b = ip.generate(seed=42, scale=1.0, **kw)
     c = ip.generate(seed=42, scale=0.0, **kw)
@@ -175,6 +176,35 @@ def test_end_to_end_pil_in_pil_out_like_test_py():
     out = ip.generate(pil_image=img, prompt_embeds=embeds, extra_prompt_embeds=det_randn((1, 77, cd), 6), num_samples=1,
                       seed=42, num_inference_steps=2, guidance_scale=5.0, height=256, width=320, output_type="pil")
     assert isinstance(out[0], Image.Image) and out[0].size == (320, 256)
+    # --- the reference's own call, verbatim (test.py:28-43): string prompts, stray number_class_crossattention=,
+    #     NO output_type (the reference pipeline defaults to "pil", custom_pipelines.py:42), then images[0].save() ---
+    def fake_text_encoder(prompt, num_images_per_prompt=1, do_classifier_free_guidance=True, negative_prompt=None):
+        # no tokenizer vocabulary offline: deterministic embeddings keyed by the strings (the step before the path)
+        def emb(txt, n, d):
+            sd = sum(txt.encode()) if isinstance(txt, str) else sum(sum(t.encode()) for t in txt)
+            return det_randn((num_images_per_prompt, n, d) if n else (num_images_per_prompt, d), sd % 1000)
+        return (emb(prompt, 77, cd), emb(negative_prompt or "", 77, cd), emb(prompt, 0, ocfg.pooled_dim),
+                emb(negative_prompt or "", 0, ocfg.pooled_dim))
+    pipe.text_encoder = fake_text_encoder
+    ip_model, input_image, number_class_crossattention = ip, img.resize((512, 512)), ha
+    prompt, extra_text = "a photo of three cats", "three cats"
+    images = ip_model.generate(
+        pil_image=input_image,
+        prompt=prompt,
+        negative_prompt="text, watermark, lowres, low quality, worst quality, deformed, glitch, low contrast, noisy, saturation, blurry",
+        scale=1.0,
+        guidance_scale=5.0,
+        num_samples=1,
+        num_inference_steps=30,
+        seed=42,
+        extra_text=extra_text,
+        number_class_crossattention=number_class_crossattention
+    )
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        output_path = os.path.join(td, "output.png")
+        images[0].save(output_path)
+        assert Image.open(output_path).size == (256, 256)       # default_sample_size 32 x vae_scale_factor 8
     plus = IPAdapterPlusXL(pipe, None, None, DEV, num_tokens=16, dtype=dtype, image_encoder=clip, clip_image_processor=proc)
     assert plus.clip_hidden_size == 64
     a, b = plus.get_image_embeds(pil_image=img)                # penultimate hidden states -> Resampler (ip_adapter.py:405-417)
@@ -266,7 +296,8 @@ def test_ipadapter_plus_xl_generate_call_sequence():
     embeds = (det_randn((1, 77, cd), 1), det_randn((1, 77, cd), 2), det_randn((1, ocfg.pooled_dim), 3),
               det_randn((1, ocfg.pooled_dim), 4))
     kw = dict(clip_hidden_states=det_randn((1, 257, 128), 5), uncond_clip_hidden_states=det_randn((1, 257, 128), 6),
-              prompt_embeds=embeds, num_samples=1, num_inference_steps=2, guidance_scale=5.0, height=256, width=256)
+              prompt_embeds=embeds, num_samples=1, num_inference_steps=2, guidance_scale=5.0, height=256, width=256,
+              output_type="latent")
     a = ip.generate(seed=7, scale=1.0, **kw)
     b = ip.generate(seed=7, scale=1.0, **kw)
     c = ip.generate(seed=7, scale=0.3, **kw)
@@ -325,3 +356,49 @@ def test_ipadapter_plus_and_full_surface():
     kw = pipe.calls[-1]
     assert len(imgs) == 2 and kw["prompt_embeds"].shape == (2, 77 + 65, ocfg.cross_attention_dim)
     assert kw["guidance_scale"] == 7.5 and kw["num_inference_steps"] == 3 and "pooled_prompt_embeds" not in kw
+
+
+def test_generate_pns_two_stage_with_clip_judge():
+    """PNS as the reference's figure draws it (README.md:27, assets/1.png): candidate seeds -> 10-step previews ->
+    judge -> best noise -> 30-step final, here with the default CLIP-space judge (decoded preview vs the
+    harmony-fused image embedding) on reduced configs; deterministic, and the final image is the 30-step denoise of
+    the winning seed."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+    from imagharmony_amd import pns
+    from imagharmony_amd.ip_adapter import IPAdapterXL
+    from imagharmony_amd.modules import HarmonyAttention
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    from imagharmony_amd.vae import AutoencoderKL, VAEConfig
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    vae = AutoencoderKL(VAEConfig(block_out_channels=(64, 64, 128, 128), layers_per_block=1, sample_size=256)).init_random_(2).to(DEV, dtype)
+    pipe = StableDiffusionXLCustomPipeline(hu, device=DEV, dtype=dtype, vae=vae)
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                                          num_attention_heads=4, image_size=32, patch_size=8,
+                                                          projection_dim=128)).eval().to(DEV, dtype)
+    proc = CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32})
+    img = Image.fromarray((np.random.RandomState(0).rand(48, 40, 3) * 255).astype("uint8"))
+    cd = ocfg.cross_attention_dim
+    ha = det_fill(HarmonyAttention(image_hidden_size=128, text_context_dim=cd, inter_dim=512, cross_heads=8,
+                                   reshape_blocks=8, cross_value_dim=64), 3)
+    ip = IPAdapterXL(pipe, None, None, DEV, num_tokens=4, inference=True, number_class_crossattention=ha, dtype=dtype,
+                     image_encoder=clip, clip_image_processor=proc)
+    det_fill(ip.image_proj_model, 5)
+    embeds = (det_randn((1, 77, cd), 1), det_randn((1, 77, cd), 2), det_randn((1, ocfg.pooled_dim), 3),
+              det_randn((1, ocfg.pooled_dim), 4))
+    kw = dict(pil_image=img, prompt_embeds=embeds, extra_prompt_embeds=det_randn((1, 77, cd), 6), preview_steps=10,
+              num_inference_steps=30, guidance_scale=5.0, height=256, width=256)
+    seeds = [3, 9, 27, 81]
+    r1 = ip.generate_pns(seeds, **kw)
+    r2 = ip.generate_pns(seeds, batch=2, **kw)               # two candidates stacked per forward: same winner
+    assert isinstance(r1["images"][0], Image.Image) and r1["images"][0].size == (256, 256)
+    assert r1["best_seed"] == r2["best_seed"] and r1["best_seed"] in seeds
+    assert torch.isfinite(r1["scores"]).all() and r1["scores"].abs().max() <= 1.0 + 1e-3
+    assert r1["scores"].unique().numel() == len(seeds)
+    assert (r1["scores"] - r2["scores"]).abs().max() < 5e-2      # batched rows differ from batch-1 rows by rounding only
+    # the returned latent is the 30-step denoise of the winning noise
+    direct = ip.generate_pns([r1["best_seed"]], output_type="latent", **kw)["latents"]
+    assert torch.equal(direct, r1["latents"])

@@ -15,17 +15,33 @@ def _fake_denoise(noise):
     return noise * 0.5 + noise.mean(dim=(1, 2, 3), keepdim=True)      # per candidate: batching must not mix them
 
 
-def _worker(rank, world, port, seeds, q, batch=1):
+def _tiny_judge():
+    """the default CLIP-space judge on a tiny random CLIP vision model (transformers) and a stand-in decoder"""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=16, patch_size=8,
+                                                          projection_dim=24)).eval()
+    decode = lambda z: torch.tanh(torch.nn.functional.interpolate(z[:, :3], scale_factor=4.0, mode="nearest"))
+    target = torch.randn(1, 24, generator=torch.Generator().manual_seed(5))
+    return pns.ClipPreferenceJudge(decode, clip, target)
+
+
+def _worker(rank, world, port, seeds, q, batch=1, judge=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lin = torch.nn.Linear(4, 4)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
         with torch.no_grad():
-            lin.weight.fill_(float(rank + 1))
-        pns.broadcast_module_(lin, src=0)
-        r = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0, batch=batch)
-        q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].sum().item(), lin.weight[0, 0].item(), r["owner"]))
+            for p in net.parameters():
+                p.fill_(float(rank + 1))
+        n_coll = pns.broadcast_module_(net, src=0, bucket_bytes=64)     # tiny buckets: several flat collectives
+        assert 1 < n_coll < len(list(net.parameters())) + len(list(net.buffers()))
+        assert all(bool((p == 1.0).all()) for p in net.parameters())
+        scorer = _tiny_judge() if judge else pns.default_scorer
+        r = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), scorer=scorer, final_fn=lambda n: _fake_denoise(n) + 1.0, batch=batch)
+        q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].sum().item(), net[0].weight[0, 0].item(), r["owner"]))
     finally:
         dist.destroy_process_group()
 
@@ -41,17 +57,22 @@ def _free_port():
 import pytest
 
 
-@pytest.mark.parametrize("batch", [1, 2])
-def test_pns_world2_matches_single_process(batch):
-    """batch = candidates stacked per denoise call on a rank (configs[4]: 4 per GPU): same scores, same winner"""
+@pytest.mark.parametrize("batch,judge", [(1, False), (2, False), (2, True)])
+def test_pns_world2_matches_single_process(batch, judge):
+    """batch = candidates stacked per denoise call on a rank (configs[4]: 4 per GPU): same scores, same winner;
+    judge=True: the default CLIP-space judge (decode -> CLIP embedding -> cosine to the fused target) as the scorer"""
     seeds = [11, 7, 3, 19, 5, 23, 2]
-    single = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0)
-    batched = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=lambda n: _fake_denoise(n) + 1.0, batch=3)
-    assert batched["best_seed"] == single["best_seed"] and torch.equal(batched["scores"], single["scores"])
+    scorer = _tiny_judge() if judge else pns.default_scorer
+    single = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), scorer=scorer, final_fn=lambda n: _fake_denoise(n) + 1.0)
+    batched = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), scorer=scorer, final_fn=lambda n: _fake_denoise(n) + 1.0, batch=3)
+    assert batched["best_seed"] == single["best_seed"]
+    assert torch.allclose(batched["scores"], single["scores"], atol=1e-6)
+    if judge:
+        assert single["scores"].abs().max() <= 1.0 + 1e-5 and single["scores"].unique().numel() == len(seeds)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, seeds, q, batch)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, seeds, q, batch, judge)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
@@ -60,7 +81,7 @@ def test_pns_world2_matches_single_process(batch):
         assert p.exitcode == 0
     for rank, best, scores, lat_sum, w00, owner in res:
         assert best == single["best_seed"]
-        assert scores == single["scores"].tolist()
+        assert torch.allclose(torch.tensor(scores), single["scores"], atol=1e-6)
         assert abs(lat_sum - single["latents"].sum().item()) < 1e-4
         assert w00 == 1.0                                  # weights broadcast from rank 0
         assert owner == seeds.index(best) % 2

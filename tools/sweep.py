@@ -88,7 +88,7 @@ def summarize(rec, ms, wall_ms, label):
 def sweep_shapes(rec, dtype):
     l = rec.lib
     shapes = collections.OrderedDict()
-    for (tag, kind, descr, fl, by_, shape) in rec.tags:
+    for (tag, kind, descr, fl, by_, shape, *rest) in rec.tags:
         if kind == L.OP_GEMM and shape is not None:
             shapes.setdefault(shape, descr)
     print(f"{len(shapes)} distinct GEMM/conv shapes", flush=True)
