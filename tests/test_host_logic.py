@@ -194,5 +194,11 @@ def test_pipeline_argument_checks_need_no_gpu():
     """eta != 0 is refused (the device-resident step is the deterministic update)"""
     from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
     pipe = StableDiffusionXLCustomPipeline.__new__(StableDiffusionXLCustomPipeline)
+    pipe.vae = pipe.vae_decode = None
     with pytest.raises(NotImplementedError, match="eta"):
-        pipe(prompt_embeds=torch.zeros(1, 81, 8), eta=0.5)
+        pipe(prompt_embeds=torch.zeros(1, 81, 8), eta=0.5, output_type="latent")
+    # the reference's default output_type is "pil" (custom_pipelines.py:42): without a VAE that is refused up front
+    with pytest.raises(NotImplementedError, match="needs a VAE"):
+        pipe(prompt_embeds=torch.zeros(1, 81, 8))
+    import inspect
+    assert inspect.signature(StableDiffusionXLCustomPipeline.__call__).parameters["output_type"].default == "pil"
