@@ -122,41 +122,41 @@ class AttnProcessor2_0(nn.Module):
         super().__init__()
 
     # -- recorded / fused path ------------------------------------------------------------
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None, rowstats=False):
-        """x: [B*L, C].  Returns to_out(attention(x)) (+ residual)  [, row-statistics partials if rowstats].
-        ln = (norm module, stats [M,2]): x is the UN-normalised residual stream and LayerNorm is folded into the
-        projections; otherwise x is already layer-normed.
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None):
+        """x: [B*L, C].  Returns to_out(attention(x)) (+ residual).
+        ln = norm module: x is the UN-normalised residual stream and that LayerNorm is folded into the projections
+        (statistics taken inside the GEMM); otherwise x is already layer-normed.
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
         C_ = x.shape[1]
         H = attn.heads
         if L_ % 64 and lk is None:
-            return self._emit_ragged(ctx, attn, x, B, L_, residual, ln, rowstats)
+            return self._emit_ragged(ctx, attn, x, B, L_, residual, ln)
         if ln is None:
             wqk, wv = _packed_qk(attn, ctx), _w(attn.to_v, ctx)
             g1, g2 = dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM)
         else:
-            norm, stat = ln
+            norm = ln
             key = (attn.to_q.weight.data_ptr(), attn.to_v.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
             fq, fv = _cached(attn, "_imh_ln_qkv", key, lambda: (
                 fold_ln(torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0), norm, ctx),
                 fold_ln(attn.to_v.weight, norm, ctx)))
-            g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(stat, fq[1], fq[2]))
-            g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(stat, fv[1], fv[2]))
+            g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps))
+            g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], norm.eps))
         # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch
         qk, vt = ctx.gemm_dual(g1, g2, descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="self.to_out", rowstats=rowstats)
+                       descr="self.to_out")
         ctx.free(qk); ctx.free(vt); ctx.free(ao)
         return out
 
-    def _emit_ragged(self, ctx, attn, x, B, L_, residual, ln, rowstats):
+    def _emit_ragged(self, ctx, attn, x, B, L_, residual, ln):
         """Token counts that are not a multiple of the 64-key tile (e.g. 1152x896 -> 36x28 = 1008 tokens at the
         deepest level): every batch gets its own 64-padded slab of [Q|K] and V^T (dedicated zero-initialised
         buffers, so the padded keys stay finite for ever; they are masked in the kernel), projections run per batch."""
-        if ln is not None or rowstats:
+        if ln is not None:
             raise L.ImhError("ragged token counts are not supported together with the folded-LayerNorm path")
         if L_ % 16:
             raise L.ImhError(f"self-attention over {L_} tokens: the fused path needs a multiple of 16 "
@@ -230,16 +230,16 @@ class IPAttnProcessor2_0(nn.Module):
             kv.k2, kv.vt2, kv.lk2, kv.lk2_pad = project_kv(ctx, ip, _w(self.to_k_ip, ctx), _w(self.to_v_ip, ctx))
         return kv
 
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None, rowstats=False):
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None):
         C_ = x.shape[1]
         H = attn.heads
         if ln is None:
             q = ctx.gemm(x, _w(attn.to_q, ctx), descr="cross.to_q")
         else:       # x is the un-normalised stream; LayerNorm folded into to_q
-            norm, stat = ln
+            norm = ln
             key = (attn.to_q.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
             fq = _cached(attn, "_imh_ln_q", key, lambda: fold_ln(attn.to_q.weight, norm, ctx))
-            q = ctx.gemm(x, fq[0], flags=L.GF_LN_ROW, ln=(stat, fq[1], fq[2]), descr="cross.to_q")
+            q = ctx.gemm(x, fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps), descr="cross.to_q")
         ao = ctx.new(B * L_, C_)
         if kv.k2 is not None:
             ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
@@ -250,7 +250,7 @@ class IPAttnProcessor2_0(nn.Module):
             ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
                           descr="cross.attn")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="cross.to_out", rowstats=rowstats)
+                       descr="cross.to_out")
         ctx.free(q); ctx.free(ao)
         return out
 

@@ -33,7 +33,7 @@ int check_launch(const char* what) {
 static GemmParams to_gemm(const imh_gemm_args* a) {
     GemmParams p;
     p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
-    p.residual = a->residual; p.ln_stat = a->ln_stat; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.stats_out = a->stats_out;
+    p.residual = a->residual; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.ln_eps = a->ln_eps;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
@@ -48,13 +48,18 @@ static int do_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, hipStrea
     if (a->conv || b->conv || a->dtype != b->dtype) { set_error("gemm_dual: both problems must be plain GEMMs of one dtype"); return IMH_ERR_ARG; }
     int bm = a->bm, bn = a->bn;
     if (bm <= 0 || bn <= 0 || bm > 128) { bm = 128; bn = 64; }
+    for (const imh_gemm_args* g : {a, b})
+        if ((g->flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!g->ln_s || !g->ln_c || !(g->ln_eps > 0.f))) {
+            set_error("gemm_dual: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG;
+        }
     return gemm_dual_launch(to_gemm(a), to_gemm(b), a->dtype, bm, bn, s);
 }
 
 static int do_gemm(const imh_gemm_args* a, hipStream_t s) {
     if (!a || !a->X || !a->W || !a->Y) { set_error("gemm: null pointer argument"); return IMH_ERR_ARG; }
     GemmParams p = to_gemm(a);
-    if ((p.flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!p.ln_stat || !p.ln_s || !p.ln_c)) { set_error("gemm: folded LayerNorm needs ln_stat / ln_s / ln_c"); return IMH_ERR_ARG; }
+    if ((p.flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!p.ln_s || !p.ln_c || !(p.ln_eps > 0.f))) { set_error("gemm: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG; }
+    if ((p.flags & IMH_GF_LN_ROW) && (p.flags & IMH_GF_LN_COL)) { set_error("gemm: IMH_GF_LN_ROW and IMH_GF_LN_COL are exclusive"); return IMH_ERR_ARG; }
     int bm = a->bm, bn = a->bn;
     if (bm <= 0 || bn <= 0 || p.splits <= 0) {
         int hb, hn, hs;
@@ -151,10 +156,6 @@ static int run_op(const imh_op& o, hipStream_t s) {
             if (!o.u.norm.x || !o.u.norm.y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
             return layernorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
         }
-        case IMH_OP_LN_STATS: {
-            if ((!o.u.norm.x && !o.u.norm.partial) || !o.u.norm.y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
-            return layernorm_stats_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
-        }
         case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
         case IMH_OP_ATTN_SMALL: return do_attn_small(&o.u.sattn, s);
         case IMH_OP_GEMM_DUAL: return do_gemm_dual(&o.u.gemm2[0], &o.u.gemm2[1], s);
@@ -173,7 +174,6 @@ static size_t args_size(int kind) {
         case IMH_OP_GEMM: return sizeof(imh_gemm_args);
         case IMH_OP_ATTN: return sizeof(imh_attn_args);
         case IMH_OP_GROUPNORM:
-        case IMH_OP_LN_STATS:
         case IMH_OP_LAYERNORM: return sizeof(imh_norm_args);
         case IMH_OP_EW: return sizeof(imh_ew_args);
         case IMH_OP_ATTN_SMALL: return sizeof(imh_small_attn_args);
@@ -214,11 +214,6 @@ size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups) { return 
 int imh_layernorm(const imh_norm_args* a, void* stream) {
     if (!a || !a->x || !a->y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
     return layernorm_launch(to_norm(a), a->dtype, (hipStream_t)stream);
-}
-
-int imh_layernorm_stats(const imh_norm_args* a, void* stream) {
-    if (!a || (!a->x && !a->partial) || !a->y) { set_error("layernorm_stats: null pointer argument"); return IMH_ERR_ARG; }
-    return layernorm_stats_launch(to_norm(a), a->dtype, (hipStream_t)stream);
 }
 
 int imh_elementwise(int op, const imh_ew_args* a, void* stream) { return do_ew(op, a, (hipStream_t)stream); }

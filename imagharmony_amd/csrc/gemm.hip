@@ -27,7 +27,12 @@ namespace imh {
 int g_xcd_mode = 0;
 
 
-template <typename T, int BM, int BN, bool CONV>
+// LN: 0 = none; 1 = folded LayerNorm with the token rows as the X operand (GF_LN_ROW); 2 = token rows as the W operand
+// (GF_LN_COL, the swapped-operand V^T projection).  For LN != 0 the row statistics (sum, sum of squares over K) are
+// accumulated INSIDE the K loop from the operand fragments the MFMAs consume anyway (8 v_dot2c per fragment, issued
+// under the MFMAs), so BasicTransformerBlock.norm1/2/3 cost no launch, no pass over the residual stream and no
+// statistics buffer.  Needs splits == 1 (the whole K range in one workgroup).
+template <typename T, int BM, int BN, bool CONV, int LN>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, const int z) {
     constexpr int FM = BM / 32;   // 16-row token fragments per wave
     constexpr int FN = BN / 32;   // 16-row weight fragments per wave
@@ -143,6 +148,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NS = LN == 1 ? FM : (LN == 2 ? FN : 1);
+    float st_s[NS], st_q[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
 
     if (kt0 < kt1) {
         stage(0, kt0);
@@ -164,6 +173,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+                if constexpr (LN == 1) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
+                }
+                if constexpr (LN == 2) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) frag_stats(wf[j], st_s[j], st_q[j]);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -173,78 +190,76 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
 
     // ---- epilogue: lane owns columns nb .. nb+4*FN-1 of row m ----
     const int nb = n0 + out_col(lane, wn, BN);
-    const bool row_stats = p.stats_out != nullptr;     // workgroup-uniform
     // folded-LayerNorm operands of this lane's columns: fetched once here (after the K loop, so they cost no
     // registers inside it), not once per output row
     float lnpre[8 * FN];
     const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
+    LnArgs<4 * FN> ln;
+    if constexpr (LN != 0) {
+        // every lane of a 16-lane row holds the partial sums of fragment row (lane & 15) over ITS 8-element k-slices:
+        // combine the four lane groups (permlane swaps, no LDS), then mean / rstd per fragment row
+        const float invk = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float su = xor32_sum(xor16_sum(st_s[i]));
+            const float sq = xor32_sum(xor16_sum(st_q[i]));
+            const float mean = su * invk;
+            st_s[i] = mean;
+            st_q[i] = rsqrtf(fmaxf(sq * invk - mean * mean, 0.f) + p.ln_eps);
+        }
+        if constexpr (LN == 2) {
+            // weight-fragment row rho of fragment j is tile column (rho>>2)*4FN + j*4 + (rho&3) of the wave's slab; this
+            // lane stores columns g*4FN + j*4 + r (g = lane>>4): fetch them from lane rho = 4g + r of its own 16-group
+            const int g = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int src = (lane & 48) | (g * 4 + r);
+                    ln.cm[j * 4 + r] = __shfl(st_s[j], src, 64);
+                    ln.cr[j * 4 + r] = __shfl(st_q[j], src, 64);
+                }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + out_row(lane, wm, BM, i);
-        const bool active = m < p.M && nb < p.N;
-        if (!active && !row_stats) continue;
+        if (m >= p.M || nb >= p.N) continue;
         float v[4 * FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
-        if (active) {
-            if (p.splits > 1) {
-                float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
-                if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+        if (p.splits > 1) {
+            float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+            if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
 #pragma unroll
-                    for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
-                }
+                for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
             } else {
-                epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre);   // leaves the final (un-rounded) values in v
-            }
-        }
-        if (row_stats) {
-            // Row statistics of the stored tile for the next LayerNorm: one (sum, M2) partial per 32-column slot
-            // (M2 = squared deviations from the slot mean; combined exactly by ln_finalize_kernel, norm.hip).
-            // A slot is owned by LPS adjacent column-quads of one wave: 2 (FN = 4) or 4 (FN = 2) lanes 16 apart.
-            constexpr int LPS = 32 / (4 * FN);
-            static_assert(LPS == 2 || LPS == 4, "row statistics need 64- or 128-column tiles");
-            const int col0 = nb & ~31;
-            const int nval = min(32, p.N - col0);
-            float r[4 * FN];
-            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4 * FN; ++q) {
-                r[q] = (active && nb + q < p.N) ? to_f32(from_f32<T>(v[q])) : 0.f;
-                sum += r[q];
+                for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
-            sum = xor16_sum(sum);
-            if (LPS == 4) sum = xor32_sum(sum);
-            const float mean = sum / (float)max(nval, 1);
-            float m2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4 * FN; ++q)
-                if (active && nb + q < p.N) { const float d = r[q] - mean; m2 += d * d; }
-            m2 = xor16_sum(m2);
-            if (LPS == 4) m2 = xor32_sum(m2);
-            if (((lane >> 4) & (LPS - 1)) == 0 && m < p.M && col0 < p.N)
-                *(float2*)(p.stats_out + 2 * ((size_t)(col0 >> 5) * p.M + m)) = make_float2(sum, m2);
+        } else {
+            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }     // fragment i's row (lane & 15) IS output row m
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr);
         }
     }
     if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, gridDim.x, tid, 256);
 }
 
-template <typename T, int BM, int BN, bool CONV>
+template <typename T, int BM, int BN, bool CONV, int LN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-    gemm_body<T, BM, BN, CONV>(p, blockIdx.x, blockIdx.y);
+    gemm_body<T, BM, BN, CONV, LN>(p, blockIdx.x, blockIdx.y);
 }
 
 // Two independent problems in ONE launch (e.g. self-attention's [Q|K] = x [Wq;Wk]^T and V^T = Wv x^T, which
 // share x): workgroups [0, grid_a) run problem a, the rest problem b.  Halves the launch count of the pair and
 // lets the two sub-chip-sized grids fill the machine together.
-template <typename T, int BM, int BN>
+// LNP: false = plain problems; true = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both).
+template <typename T, int BM, int BN, bool LNP>
 __global__ __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
-    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false>(a, blockIdx.x, 0);
-    else gemm_body<T, BM, BN, false>(b, blockIdx.x - grid_a, 0);
+    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP ? 1 : 0>(a, blockIdx.x, 0);
+    else gemm_body<T, BM, BN, false, LNP ? 2 : 0>(b, blockIdx.x - grid_a, 0);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
@@ -283,7 +298,9 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
     dim3 grid(tiles, p.splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV>), grid, dim3(256), smem, stream, q);
+    if (!CONV && (p.flags & GF_LN_ROW)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 1>), grid, dim3(256), smem, stream, q);
+    else if (!CONV && (p.flags & GF_LN_COL)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 2>), grid, dim3(256), smem, stream, q);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 0>), grid, dim3(256), smem, stream, q);
     return check_launch("gemm_kernel");
 }
 
@@ -325,7 +342,8 @@ static int launch_dual_tile(const GemmParams& a, const GemmParams& b, hipStream_
     xcd_partition(qa, BM, BN, &ga);
     xcd_partition(qb, BM, BN, &gb);
     const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
-    hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    if (a.flags & GF_LN_ROW) hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, true>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    else hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, false>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
     return check_launch("gemm_dual_kernel");
 }
 
@@ -349,6 +367,11 @@ int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipS
         if (p->rowadd && p->rows_per_batch <= 0) { set_error("gemm_dual: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
     }
     a.splits = b.splits = 1;
+    const int lnf = GF_LN_ROW | GF_LN_COL;
+    if (((a.flags | b.flags) & lnf) && !((a.flags & lnf) == GF_LN_ROW && (b.flags & lnf) == GF_LN_COL)) {
+        set_error("gemm_dual: folded LayerNorm needs problem a in row form and problem b in column form");
+        return IMH_ERR_ARG;
+    }
     if (((a.flags | b.flags) & GF_VT_PERM) && bn != 128) bn = 128;     // the permutation lives in 16-column groups
     if (dtype == IMH_DT_BF16) return launch_dual_typed<bf16_t>(a, b, bm, bn, stream);
     if (dtype == IMH_DT_F16) return launch_dual_typed<f16_t>(a, b, bm, bn, stream);
@@ -385,8 +408,8 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if (p.stats_out && (p.splits > 1 || bm >= 256 || (p.flags & (GF_GEGLU | GF_OUT_F32)))) {
-        set_error("gemm: stats_out needs a plain 64/128 tile, splits == 1, no GEGLU / fp32 output (bm=%d splits=%d flags=%d)", bm, p.splits, p.flags);
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || bm >= 256 || conv)) {
+        set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);

@@ -92,26 +92,25 @@ __device__ __forceinline__ void stv(T* p, const float* v) {
     }
 }
 
-// Folded-LayerNorm operands that depend only on the lane's column range: fetched ONCE per lane (before the K
-// loop, so their latency hides under it) instead of once per output row in the epilogue.  Returns whether
-// `pre` (2*NV floats) is valid: row form -> s[NV] then c[NV]; column form -> (mean, rstd) pairs.
+// Folded LayerNorm (GF_LN_ROW / GF_LN_COL).  The statistics of the un-normalised token rows come from the K loop
+// itself (frag_stats on the MFMA operand fragments, gemm.hip): LnArgs carries what one lane needs for one output row.
+//   row form:  y[m, n] = rstd_m * (acc - mean_m * s_n) + c_n      (tokens = X rows; s, c per output column)
+//   col form:  y[m, n] = rstd_n * (acc - mean_n * s_m) + c_m      (tokens = W rows = output columns; s, c per row)
+template <int NV>
+struct LnArgs {
+    float mean, rstd;            // row form: statistics of output row m
+    float cm[NV], cr[NV];        // col form: (mean, rstd) of the lane's NV output columns
+};
+
+// s_n, c_n of the lane's column range, fetched once per lane (row form); false if the range is ragged
 template <int NV>
 __device__ __forceinline__ bool ln_preload(const GemmParams& p, int nb, float (&pre)[2 * NV]) {
-    if (!(p.flags & (GF_LN_ROW | GF_LN_COL)) || nb + NV > p.N) return false;
-    if (p.flags & GF_LN_ROW) {
+    if (!(p.flags & GF_LN_ROW) || nb + NV > p.N) return false;
 #pragma unroll
-        for (int q0 = 0; q0 < NV; q0 += 4) {
-            const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + q0), c4 = *(const f32x4*)(p.ln_c + nb + q0);
+    for (int q0 = 0; q0 < NV; q0 += 4) {
+        const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + q0), c4 = *(const f32x4*)(p.ln_c + nb + q0);
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) { pre[q0 + e2] = s4[e2]; pre[NV + q0 + e2] = c4[e2]; }
-        }
-    } else {
-#pragma unroll
-        for (int q0 = 0; q0 < 2 * NV; q0 += 4) {
-            const f32x4 st = *(const f32x4*)(p.ln_stat + 2 * nb + q0);
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) pre[q0 + e2] = st[e2];
-        }
+        for (int e2 = 0; e2 < 4; ++e2) { pre[q0 + e2] = s4[e2]; pre[NV + q0 + e2] = c4[e2]; }
     }
     return true;
 }
@@ -120,7 +119,8 @@ __device__ __forceinline__ bool ln_preload(const GemmParams& p, int nb, float (&
 // Fast path (whole vector in range, 16-B aligned operands): vector loads/stores only.
 template <typename T, int FN>
 __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&v)[4 * FN], int m, int nb,
-                                                   const float (&lnpre)[8 * FN], const bool have_pre) {
+                                                   const float (&lnpre)[8 * FN], const bool have_pre,
+                                                   const LnArgs<4 * FN>* ln = nullptr) {
     constexpr int NV = 4 * FN;
     constexpr int NH = NV / 2;
     const T* bias = (const T*)p.bias;
@@ -130,41 +130,20 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
     const bool geglu = p.flags & GF_GEGLU;
     const bool fast = (nb + NV <= N) && !(p.ldy & 7) && (!res || !(p.ldr & 7)) && (!rowadd || !(p.ldra & 7));
     float t[NV];
-    if (p.flags & (GF_LN_ROW | GF_LN_COL)) {
-        const bool whole = nb + NV <= N;
+    if (ln && (p.flags & (GF_LN_ROW | GF_LN_COL))) {
         if (p.flags & GF_LN_ROW) {       // y = rstd_m * (acc - mean_m * s_n) + c_n
-            const float mean = p.ln_stat[2 * m], rstd = p.ln_stat[2 * m + 1];
+            const float mean = ln->mean, rstd = ln->rstd;
             if (have_pre) {              // s_n, c_n preloaded once per lane by the caller (ln_preload)
 #pragma unroll
                 for (int q = 0; q < NV; ++q) v[q] = rstd * (v[q] - mean * lnpre[q]) + lnpre[NV + q];
-            } else if (whole) {
-#pragma unroll
-                for (int q0 = 0; q0 < NV; q0 += 4) {
-                    const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + q0), c4 = *(const f32x4*)(p.ln_c + nb + q0);
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) v[q0 + e2] = rstd * (v[q0 + e2] - mean * s4[e2]) + c4[e2];
-                }
             } else {
 #pragma unroll
                 for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] = rstd * (v[q] - mean * p.ln_s[nb + q]) + p.ln_c[nb + q];
             }
         } else {                         // y = rstd_n * (acc - mean_n * s_m) + c_m
             const float sm = p.ln_s[m], cm = p.ln_c[m];
-            if (have_pre) {              // (mean_n, rstd_n) pairs preloaded
 #pragma unroll
-                for (int q = 0; q < NV; ++q) v[q] = lnpre[2 * q + 1] * (v[q] - lnpre[2 * q] * sm) + cm;
-            } else if (whole) {
-#pragma unroll
-                for (int q0 = 0; q0 < NV; q0 += 2) {
-                    const f32x4 st = *(const f32x4*)(p.ln_stat + 2 * (nb + q0));     // (mean, rstd) x 2 columns
-                    v[q0] = st[1] * (v[q0] - st[0] * sm) + cm;
-                    v[q0 + 1] = st[3] * (v[q0 + 1] - st[2] * sm) + cm;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NV; ++q)
-                    if (nb + q < N) v[q] = p.ln_stat[2 * (nb + q) + 1] * (v[q] - p.ln_stat[2 * (nb + q)] * sm) + cm;
-            }
+            for (int q = 0; q < NV; ++q) v[q] = ln->cr[q] * (v[q] - ln->cm[q] * sm) + cm;
         }
     }
     if ((p.flags & GF_VT_PERM) && FN == 4) {   // V^T key permutation: swap the 2nd and 3rd run of 4

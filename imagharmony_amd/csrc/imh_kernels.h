@@ -13,11 +13,11 @@ struct GemmParams {
     const void* bias;      // [N] or null
     const void* rowadd;    // [M / rows_per_batch, N] broadcast add (time-embedding projection) or null
     const void* residual;  // [M, ldr] or null (added after activation / GEGLU)
-    // LayerNorm folded into the GEMM (GF_LN_ROW / GF_LN_COL): y = rstd*(acc - mean*ln_s) + ln_c, W pre-scaled by gamma
-    const float* ln_stat;  // [rows, 2] (mean, rstd) of the un-normalised operand rows (row form: per m; col form: per n)
+    // LayerNorm folded into the GEMM (GF_LN_ROW / GF_LN_COL): y = rstd*(acc - mean*ln_s) + ln_c, W pre-scaled by gamma;
+    // (mean, rstd) of the un-normalised token rows are taken INSIDE the K loop from the MFMA operand fragments
     const float* ln_s;     // sum_k gamma_k W[.,k]   (row form: per n; col form: per m)
     const float* ln_c;     // sum_k beta_k  W[.,k]   (same indexing as ln_s)
-    float* stats_out;      // optional [ceil(N/32)][M][2] (sum, M2) slot partials of the output rows (see imh.h)
+    float ln_eps;
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;
@@ -82,7 +82,6 @@ struct NormParams {
 int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream);
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int layernorm_launch(const NormParams& p, int dtype, hipStream_t stream);
-int layernorm_stats_launch(const NormParams& p, int dtype, hipStream_t stream);
 
 struct EwParams {
     const void* a;

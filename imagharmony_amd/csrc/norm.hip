@@ -236,108 +236,6 @@ __global__ __launch_bounds__(256) void ln_kernel(const NormParams p) {
     }
 }
 
-// row statistics only (mean, rstd) -> fp32 [rows, 2]; the normalisation itself is folded into the consumer GEMM
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_stats_kernel(const NormParams p) {
-    typedef typename Vec<T>::v8 v8;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
-    const int C = p.C, CL = C >> 3;
-    const T* x = (const T*)p.x + (size_t)row * C;
-    float v[NCH][8];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < CL) {
-            v8 t = *(const v8*)(x + ch * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[k][e] = to_f32(t[e]); s += v[k][e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
-        }
-    }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < CL) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
-    if (lane == 0) { ((float*)p.y)[2 * row] = mean; ((float*)p.y)[2 * row + 1] = rstd; }
-}
-
-// (mean, rstd) from the producer GEMM's 32-column slot partials [nslots][rows][2] = (sum, M2 about the slot mean):
-// Chan's pairwise combination, M2 = sum_i M2_i + n_i (mean_i - mean)^2 -- as accurate as the two-pass kernel above,
-// fixed summation order.
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const NormParams p) {
-    // 32 rows per workgroup, 8 threads per row (thread sub handles slots sub, sub+8, ..: <= 8 for C <= 2048), all
-    // loads issued before the first use; a wave reads 32 consecutive rows of a slot = one 256-B line
-    __shared__ float red[2][8][32];
-    const int r32 = threadIdx.x & 31, sub = threadIdx.x >> 5;
-    const int row = blockIdx.x * 32 + r32;
-    const int C = p.C, nslots = (C + 31) >> 5;
-    const float2* part = (const float2*)p.partial;
-    float2 t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = sub + 8 * j;
-        t[j] = (row < p.rows && i < nslots) ? part[(size_t)i * p.rows + row] : make_float2(0.f, 0.f);
-    }
-    float tot = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tot += t[j].x;
-    red[0][sub][r32] = tot;
-    __syncthreads();
-    tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[0][k][r32];
-    const float mean = tot / C;
-    float m2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = sub + 8 * j;
-        if (i < nslots) {
-            const float n = (float)min(32, C - 32 * i);
-            const float d = t[j].x / n - mean;
-            m2 += t[j].y + n * d * d;
-        }
-    }
-    red[1][sub][r32] = m2;
-    __syncthreads();
-    if (sub == 0 && row < p.rows) {
-        m2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) m2 += red[1][k][r32];
-        *(float2*)((float*)p.y + 2 * row) = make_float2(mean, rsqrtf(m2 / C + p.eps));
-    }
-}
-
-int layernorm_stats_launch(const NormParams& p, int dtype, hipStream_t stream) {
-    if (!p.x) {       // finalise slot partials written by a GEMM epilogue (imh_gemm_args.stats_out)
-        if (!p.partial || p.C <= 0 || p.C > 2048 || p.rows <= 0) { set_error("layernorm_stats: partials missing or C=%d > 2048 (rows=%d)", p.C, p.rows); return IMH_ERR_ARG; }
-        hipLaunchKernelGGL(ln_finalize_kernel, dim3((p.rows + 31) / 32), dim3(256), 0, stream, p);
-        return check_launch("ln_finalize_kernel");
-    }
-    if (p.C % 8 || p.C > 4096 || p.rows <= 0) { set_error("layernorm_stats: unsupported C=%d rows=%d", p.C, p.rows); return IMH_ERR_SHAPE; }
-    dim3 grid((p.rows + 3) / 4);
-    const int cl = p.C >> 3;
-#define IMH_LNS(TT) do { if (cl <= 128) hipLaunchKernelGGL((ln_stats_kernel<TT, 2>), grid, dim3(256), 0, stream, p); \
-        else if (cl <= 256) hipLaunchKernelGGL((ln_stats_kernel<TT, 4>), grid, dim3(256), 0, stream, p); \
-        else hipLaunchKernelGGL((ln_stats_kernel<TT, 8>), grid, dim3(256), 0, stream, p); } while (0)
-    if (dtype == IMH_DT_BF16) IMH_LNS(bf16_t);
-    else if (dtype == IMH_DT_F16) IMH_LNS(f16_t);
-    else { set_error("layernorm_stats: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
-#undef IMH_LNS
-    return check_launch("ln_stats_kernel");
-}
-
 template <typename T>
 static int ln_typed(const NormParams& p, hipStream_t stream) {
     const int cl = p.C >> 3;

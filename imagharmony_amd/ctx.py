@@ -134,8 +134,6 @@ class Ctx:
             rc = self.lib.imh_layernorm(C.byref(args), s)
         elif kind == L.OP_ATTN_SMALL:
             rc = self.lib.imh_attention_small(C.byref(args), s)
-        elif kind == L.OP_LN_STATS:
-            rc = self.lib.imh_layernorm_stats(C.byref(args), s)
         else:
             rc = self.lib.imh_elementwise(ew_op, C.byref(args), s)
         L.check(rc, descr or f"op kind {kind}")
@@ -163,9 +161,10 @@ class Ctx:
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             ln=None, rowstats=False, _args_only=False):
+             ln=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
-        rowstats=True: also returns the fp32 slot partials of y's rows (for layernorm_stats(partials=...))."""
+        ln = (s, c, eps) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
+        (w pre-scaled by gamma; the row statistics are taken inside the kernel's K loop)."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
         K = K if K is not None else x.shape[1]
@@ -178,17 +177,14 @@ class Ctx:
         bm, bn, sp = cfg or self._config(M, N, K, 0, flags)
         if _args_only:
             sp = 1
-        part = None
-        if rowstats:                 # the statistics epilogue lives in the plain 2x2-wave tiles only
-            if sp > 1 or bm >= 256:
-                bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
-            part = self.new(((N + 31) // 32) * M * 2, dtype=torch.float32)
+        if ln is not None and (sp > 1 or bm >= 256):     # the in-loop statistics live in the plain 2x2-wave tiles only
+            bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
-        a.stats_out = self._p(part)
-        if ln is not None:           # (stat [rows,2], s, c) fp32; the caller sets GF_LN_ROW / GF_LN_COL in flags
-            a.ln_stat, a.ln_s, a.ln_c = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr()
+        if ln is not None:           # (s, c fp32, eps); the caller sets GF_LN_ROW / GF_LN_COL in flags
+            a.ln_s, a.ln_c, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+            ln = ln[:2]
         a.M, a.N, a.K = M, N, K
         a.ldx = ldx if ldx is not None else x.stride(0)
         a.ldw = ldw if ldw is not None else w.stride(0)
@@ -203,10 +199,10 @@ class Ctx:
         if _args_only:
             return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + tuple(ln or ())
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual, part) + tuple(ln or ()), shape=(M, N, K, 0, None),
+                   keep=(x, w, out, bias, rowadd, residual) + tuple(ln or ()), shape=(M, N, K, 0, None),
                    epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
                             rows_per_batch=rows_per_batch, cfg=(bm, bn, sp)))
-        return (out, part) if rowstats else out
+        return out
 
     def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
         """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch."""
@@ -317,25 +313,6 @@ class Ctx:
         es = x.element_size()
         self._emit(L.OP_LAYERNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=2.0 * es * x.numel(),
                    keep=(x, out, gamma, beta))
-        return out
-
-    def layernorm_stats(self, x, eps, descr="ln_stats", partials=None):
-        """fp32 [rows, 2] (mean, rstd) of x's rows; the normalisation is folded into the consumer GEMM (ln=...).
-        partials: the slot partials the producing gemm(rowstats=True) wrote -- x is then not read at all."""
-        self._chk(x, descr + ".x")
-        Cc = x.shape[-1]
-        rows = x.numel() // Cc
-        out = self.new(rows, 2, dtype=torch.float32)
-        a = L.NormArgs()
-        a.y = out.data_ptr()
-        a.rows, a.C, a.eps, a.dtype = rows, Cc, eps, self.dt
-        if partials is not None:
-            a.partial = partials.data_ptr()
-            self._emit(L.OP_LN_STATS, a, descr=descr, flops=0.0, nbytes=4.0 * partials.numel(), keep=(partials, out))
-        else:
-            a.x = x.data_ptr()
-            self._emit(L.OP_LN_STATS, a, descr=descr, flops=4.0 * x.numel(), nbytes=1.0 * x.element_size() * x.numel(),
-                       keep=(x, out))
         return out
 
     # ------------------------------------------------------------------ elementwise

@@ -10,9 +10,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
+ABI_VERSION = 3
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
-OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_LN_STATS = 0, 1, 2, 3, 4, 5, 6, 7
+OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL = 0, 1, 2, 3, 4, 5, 6
 EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX = range(10)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
@@ -20,7 +21,7 @@ _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 
 class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
-                ("residual", _vp), ("ln_stat", _vp), ("ln_s", _vp), ("ln_c", _vp), ("stats_out", _vp),
+                ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
@@ -71,7 +72,6 @@ SYMBOLS = [
     ("imh_groupnorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_groupnorm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("imh_layernorm", C.c_int, [C.POINTER(NormArgs), _vp]),
-    ("imh_layernorm_stats", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_elementwise", C.c_int, [C.c_int, C.POINTER(EwArgs), _vp]),
     ("imh_plan_create", _vp, []),
     ("imh_plan_destroy", None, [_vp]),
@@ -107,7 +107,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.imh_abi_version() != 2:
+    if lib.imh_abi_version() != ABI_VERSION:
         raise ImhError("libimh_hip.so ABI version mismatch")
     _lib = lib
     return lib

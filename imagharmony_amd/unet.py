@@ -29,12 +29,11 @@ from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _w
 from .ctx import Ctx
 
 
-# Fold BasicTransformerBlock.norm1/2/3 into the consumer GEMMs (exact algebra, tested): the producer GEMM writes
-# row-statistics partials in its epilogue, a one-thread-per-slot kernel finalises (mean, rstd), the consumer
-# normalises in its epilogue.  Measured on MI355X at batch 1 it is a wash (27.14 vs 27.18 ms per forward: per
-# LayerNorm, +0.6 us producer + 2.8 us finalise + 1.5-3 us consumer vs 4.9 us for the kernel it removes;
-# tools/fold_probe.py), so the plain LayerNorm kernels stay the default.
-FOLD_LAYERNORM = False
+# BasicTransformerBlock.norm1/2/3 folded into the consumer GEMMs (exact algebra, tested): the consumer takes the
+# un-normalised residual stream, accumulates each token row's (sum, sum of squares) inside its K loop from the MFMA
+# operand fragments, and normalises in its epilogue -- 210 LayerNorm launches and 0.84 GB of HBM traffic per forward
+# disappear.  False = the stand-alone LayerNorm kernel in front of every consumer (A/B and debugging).
+FOLD_LAYERNORM = True
 
 
 @dataclass
@@ -177,16 +176,14 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), Dropout(), Linear(dim * 4, dim)])
 
-    def emit(self, ctx, x, residual, ln=None, rowstats=False):
+    def emit(self, ctx, x, residual, ln=None):
         if ln is None:
             w1, b1 = self.net[0].packed(ctx)
             g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU, descr="ff.geglu")
-        else:       # x un-normalised, LayerNorm folded into the (interleaved) GEGLU projection
-            norm, stat = ln
-            w1, b1, s1, c1 = self.net[0].packed_ln(ctx, norm)
-            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU | L.GF_LN_ROW, ln=(stat, s1, c1), descr="ff.geglu")
-        out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out",
-                       rowstats=rowstats)
+        else:       # x un-normalised, LayerNorm `ln` folded into the (interleaved) GEGLU projection
+            w1, b1, s1, c1 = self.net[0].packed_ln(ctx, ln)
+            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU | L.GF_LN_ROW, ln=(s1, c1, ln.eps), descr="ff.geglu")
+        out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out")
         ctx.free(g)
         return out
 
@@ -205,43 +202,30 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = Norm(dim, 1e-5)
         self.ff = FeedForward(dim)
 
-    def emit(self, ctx, h, B, L_, kv, st, h_part=None, want_part=False):
-        """h_part: row-statistics partials of h from the GEMM that produced it (FOLD_LAYERNORM); want_part: also
-        return the partials of the result (for the next block's norm1).  Returns h3 or (h3, partials)."""
+    def emit(self, ctx, h, B, L_, kv, st):
         p1, p2 = self.attn1.processor, self.attn2.processor
         if not hasattr(p1, "emit") or not hasattr(p2, "emit"):
             raise L.ImhError("a non-HIP attention processor is installed; the fused forward needs "
                              "imagharmony_amd.attention_processor processors")
-        if FOLD_LAYERNORM and isinstance(p1, AttnProcessor2_0) and isinstance(p2, IPAttnProcessor2_0):
-            # LayerNorm never materialises and the residual stream is never re-read for statistics: the GEMM that
-            # writes h also writes per-slot (sum, M2) partials, a one-thread-per-row kernel turns them into
-            # (mean, rstd), and the normalisation is folded into the consumer GEMMs' epilogues.
-            s1 = ctx.layernorm_stats(h, self.norm1.eps, descr="norm1.stats", partials=h_part)
-            if h_part is not None:
-                ctx.free(h_part)
-            h1, part = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=(self.norm1, s1), rowstats=True)
-            ctx.free(s1); ctx.free(h)
-            s2 = ctx.layernorm_stats(h1, self.norm2.eps, descr="norm2.stats", partials=part)
-            ctx.free(part)
-            h2, part = p2.emit(ctx, self.attn2, h1, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab,
-                               ln=(self.norm2, s2), rowstats=True)
-            ctx.free(s2); ctx.free(h1)
-            s3 = ctx.layernorm_stats(h2, self.norm3.eps, descr="norm3.stats", partials=part)
-            ctx.free(part)
-            h3 = self.ff.emit(ctx, h2, residual=h2, ln=(self.norm3, s3), rowstats=want_part)
-            ctx.free(s3); ctx.free(h2)
+        ip2 = isinstance(p2, IPAttnProcessor2_0)
+        if FOLD_LAYERNORM and isinstance(p1, AttnProcessor2_0) and ip2 and L_ % 64 == 0:
+            # LayerNorm never materialises: every consumer GEMM reads the residual stream itself
+            h1 = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1)
+            ctx.free(h)
+            h2 = p2.emit(ctx, self.attn2, h1, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab, ln=self.norm2)
+            ctx.free(h1)
+            h3 = self.ff.emit(ctx, h2, residual=h2, ln=self.norm3)
+            ctx.free(h2)
             return h3
-        if h_part is not None:
-            ctx.free(h_part)
         n = _ln(ctx, self.norm1, h, "norm1")
         h1 = p1.emit(ctx, self.attn1, n, B, L_, residual=h)
         ctx.free(n); ctx.free(h)
         n = _ln(ctx, self.norm2, h1, "norm2")
         h2 = p2.emit(ctx, self.attn2, n, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab) \
-            if isinstance(p2, IPAttnProcessor2_0) else p2.emit(ctx, self.attn2, n, B, L_, residual=h1, kv=kv)
+            if ip2 else p2.emit(ctx, self.attn2, n, B, L_, residual=h1, kv=kv)
         ctx.free(n); ctx.free(h1)
         n = _ln(ctx, self.norm3, h2, "norm3")
-        h3 = self.ff.emit(ctx, n, residual=h2, rowstats=want_part)
+        h3 = self.ff.emit(ctx, n, residual=h2)
         ctx.free(n); ctx.free(h2)
         return h3
 
@@ -263,15 +247,10 @@ class Transformer2DModel(nn.Module):
         x2 = x.view(B * L_, C_)
         n = ctx.groupnorm(x.view(B, L_, C_), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps,
                           silu=False, descr="t2d.norm")
-        h, part = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in",
-                           rowstats=True) if FOLD_LAYERNORM else \
-            (ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in"), None)
+        h = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in")
         ctx.free(n)
-        nb = len(self.transformer_blocks)
-        for i, (blk, kv) in enumerate(zip(self.transformer_blocks, kvs)):
-            want = FOLD_LAYERNORM and i + 1 < nb
-            r = blk.emit(ctx, h, B, L_, kv, st, h_part=part, want_part=want)
-            h, part = r if want else (r, None)
+        for blk, kv in zip(self.transformer_blocks, kvs):
+            h = blk.emit(ctx, h, B, L_, kv, st)
         out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out")
         ctx.free(h); ctx.free(x)
         return out.view(B, Hh, Ww, C_)
@@ -647,7 +626,7 @@ class UNet2DConditionModel(nn.Module):
 
     def _pname(self, t2d, k):
         names = getattr(self, "_imh_pnames", None)
-        if names is None:
+        if names is None or id(t2d.transformer_blocks[k].attn2) not in names:      # (a deepcopy carries stale ids)
             names = {}
             for name, mod in self.named_modules():
                 if isinstance(mod, Attention) and name.endswith("attn2"):

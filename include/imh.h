@@ -19,7 +19,7 @@
  *   - dtype: IMH_DT_BF16 / IMH_DT_F16 activations+weights, fp32 accumulation everywhere.
  *   - layouts: activations are token-major / NHWC ([B, H*W, C] row-major); weights are
  *     [out, in] row-major exactly as torch.nn.Linear stores them; conv3x3 weights are
- *     pre-packed to [Cout][ky][kx][Cin] (imagharmony_amd.packing).
+ *     pre-packed to [Cout][ky][kx][Cin] (imagharmony_amd.unet.Conv2d.packed).
  */
 #ifndef IMH_H_
 #define IMH_H_
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 2
+#define IMH_ABI_VERSION 3
 
 enum imh_status {
     IMH_OK = 0,
@@ -51,8 +51,8 @@ enum imh_gemm_flags {
     IMH_GF_ACT_SILU = 4,  /* SiLU (TimestepEmbedding) */
     IMH_GF_VT_PERM = 8,   /* write the attention V^T key permutation (see imh_attention) */
     IMH_GF_OUT_F32 = 16,  /* fp32 output */
-    IMH_GF_LN_ROW = 32,   /* folded LayerNorm, statistics per output row m */
-    IMH_GF_LN_COL = 64    /* folded LayerNorm, statistics per output column n (swapped-operand V^T form) */
+    IMH_GF_LN_ROW = 32,   /* folded LayerNorm, the un-normalised token rows are X's rows (statistics per output row m) */
+    IMH_GF_LN_COL = 64    /* folded LayerNorm, the token rows are W's rows (per output column n; swapped-operand V^T form) */
 };
 
 /* ---- dense contraction ------------------------------------------------------------------
@@ -80,17 +80,14 @@ typedef struct imh_gemm_args {
     const void* residual;
     /* LayerNorm folded into the contraction (IMH_GF_LN_ROW: X rows are the un-normalised tokens; IMH_GF_LN_COL:
      * W rows are).  With W pre-scaled by gamma:  y = rstd * (acc - mean * ln_s) + ln_c  (exact algebra of
-     * LN(x) W^T; BasicTransformerBlock.norm1/2/3 never materialise).  ln_stat = [rows, 2] fp32 (mean, rstd) from
-     * imh_layernorm_stats; ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k W[.,k] (fp32). */
-    const float* ln_stat;
+     * LN(x) W^T; BasicTransformerBlock.norm1/2/3 never materialise and cost no launch).  (mean, rstd) of every
+     * token row are computed INSIDE the kernel's K loop from the operand fragments the MFMAs consume (fp32 sum and
+     * sum of squares over K), so no statistics buffer exists.  ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k
+     * W[.,k] (fp32; row form: per output column n, column form: per output row m).  Plain 64/128 tiles only,
+     * splits == 1, conv == 0. */
     const float* ln_s;
     const float* ln_c;
-    /* Optional row statistics of the OUTPUT (so that the next LayerNorm needs no pass over Y): fp32
-     * [ceil(N/32)][M][2] partials (sum, sum of squared deviations from the slot mean) of every 32-column slot of
-     * every output row, taken on the stored (rounded) values.  imh_layernorm_stats with x == NULL turns them into
-     * (mean, rstd).  Only for the plain 2x2-wave tiles (bm in {64,128}, bn in {64,128}), splits == 1, no
-     * GEGLU / fp32 output; deterministic (no atomics).  NULL = off. */
-    float* stats_out;
+    float ln_eps;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -188,10 +185,6 @@ typedef struct imh_norm_args {
 int imh_groupnorm(const imh_norm_args* a, void* stream);
 size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int imh_layernorm(const imh_norm_args* a, void* stream);
-/* row statistics only: y = fp32 [rows, 2] (mean, rstd); consumed by imh_gemm with IMH_GF_LN_ROW / _COL.
- * x != NULL: one pass over x [rows, C].  x == NULL: finalise the producer GEMM's slot partials
- * (imh_gemm_args.stats_out) given in `partial`, C = row length. */
-int imh_layernorm_stats(const imh_norm_args* a, void* stream);
 
 /* ---- small fused elementwise kernels (see csrc/elementwise.hip for the field meaning) ---- */
 enum imh_ew_op {
@@ -227,7 +220,7 @@ int imh_elementwise(int op, const imh_ew_args* a, void* stream);
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
 enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4,
-                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6, IMH_OP_LN_STATS = 7 };
+                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6 };
 
 typedef struct imh_plan imh_plan;
 

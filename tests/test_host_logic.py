@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for n in declared:
         assert hasattr(l, n)
-    assert l.imh_abi_version() == 2
+    assert l.imh_abi_version() == lib.ABI_VERSION == int(re.search(r"#define IMH_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_structs_match_header_field_order():
