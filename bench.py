@@ -276,6 +276,18 @@ def main():
         a_fl = sum(t[3] for t, m in zip(rec.tags, ms) if t[1] == L.OP_ATTN)
         a_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_ATTN)
         n_a = sum(1 for t in rec.tags if t[1] == L.OP_ATTN)
+        # the north-star kernel: one IPAttnProcessor2_0 call on an IP-active layer = [fused to_q + text attention +
+        # image-prompt attention] launch + [to_out] launch; K/V of the conditioning are step-invariant (computed once
+        # per image by prepare_conditioning and counted once per image)
+        ip_idx = [i for i, t in enumerate(rec.tags) if t[1] == L.OP_XATTN and t[2] == "cross.fused+ip"]
+        ip_us, ip_fl = [], []
+        for i in ip_idx:
+            j = next(k for k in range(i + 1, len(rec.tags)) if rec.tags[k][2] == "cross.to_out")
+            ip_us.append((ms[i] + ms[j]) * 1e3)
+            ip_fl.append(rec.tags[i][3] + rec.tags[j][3])
+        x_fl = sum(t[3] for t, m in zip(rec.tags, ms) if t[1] == L.OP_XATTN)
+        x_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_XATTN)
+        n_x = sum(1 for t in rec.tags if t[1] == L.OP_XATTN)
         # HBM bytes per launch of the family from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
@@ -309,11 +321,30 @@ def main():
                          "whole_forward_tflops": tot_fl / (dt / a.steps / a.denoise_steps) / 1e12},
             # second kernel family, same method (HIP events on the launch stream): the flash / decoupled-IP attention
             "roofline_attention": {"bound": "mfma", "achieved": a_fl / (a_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": a_fl / (a_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::attn_kernel (self + text/IP cross)",
+                                   "frac": a_fl / (a_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::attn_kernel (self-attention)",
                                    "launches_per_step": n_a, "avg_launch_us": a_ms / n_a * 1e3,
                                    "algorithmic_tflop_per_step": a_fl / 1e12,
                                    "note": "head_dim 64: softmax VALU time adds to MFMA time on a SIMD (profiles/r01_pmc_sq_gemm_attn.md)"},
         }
+        if ip_us:
+            kv_fl = 2.0 * 2 * 2 * (77 + a.ip_tokens) * 2048 * 1280          # text + ip K,V projections of one IP-active layer (CFG batch 2)
+            per_call = sum(ip_fl) / len(ip_fl) + kv_fl / a.denoise_steps       # K/V counted once per image
+            us = sum(ip_us) / len(ip_us)
+            res["roofline_ip_attn"] = {
+                "bound": "mfma", "achieved": per_call / (us * 1e-6) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": per_call / (us * 1e-6) / 1e12 / 2500.0,
+                "kernel": "imh::xattn_kernel<.., 2, ..> (to_q + norm2 + text SDPA + image-prompt SDPA + axpy, one launch) + "
+                          "imh::gemm_kernel (to_out + residual)",
+                "calls_per_step": len(ip_us), "avg_call_us": us,
+                "algorithmic_gflop_per_call": per_call / 1e9,
+                "algorithmic_gflop_per_call_survey_8d": (sum(ip_fl) / len(ip_fl) + kv_fl) / 1e9,
+                "note": "one IPAttnProcessor2_0 call on an IP-active layer (attention_processor.py:396-453); the K/V "
+                        "projections of the text / image tokens (1.70 GFLOP of SURVEY 8d's 15.97) are step-invariant, "
+                        "computed once per image and counted once per image (1/30 per step)"}
+            res["roofline_cross_attention"] = {
+                "bound": "mfma", "achieved": x_fl / (x_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": x_fl / (x_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::xattn_kernel (all 70 cross-attention layers: to_q + SDPA fused)",
+                "launches_per_step": n_x, "avg_launch_us": x_ms / n_x * 1e3, "algorithmic_tflop_per_step": x_fl / 1e12}
         if world == 1 and a.in_flight > 1:
             # extra, NOT the headline: several batch-1 candidates in flight on the one GPU (what PNS does with N > n_gpus)
             try:

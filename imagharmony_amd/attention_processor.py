@@ -7,8 +7,9 @@ same state-dict keys, same ``__call__(attn, hidden_states, encoder_hidden_states
 attention_mask=None, temb=None)`` contract (token-major ``[B, L, C]`` in and out), installed
 through ``unet.set_attn_processor`` exactly like the reference does (ip_adapter/ip_adapter.py:99-125).
 
-The arithmetic runs in libimh_hip.so: MFMA GEMMs for the projections and the flash /
-decoupled-cross-attention kernel of csrc/attention.hip.  There is no torch fallback.
+The arithmetic runs in libimh_hip.so: MFMA GEMMs for the projections, the flash kernel of
+csrc/attention.hip for self-attention, and the fused to_q + text / image-prompt cross-attention
+kernel of csrc/xattn.hip.  There is no torch fallback.
 
 Two entry points per processor:
   * ``__call__``  -- the eager plugin protocol (one call = one attention layer).
@@ -92,8 +93,10 @@ def _check_attn(attn, hidden_states, attention_mask):
 
 
 class KVCache:
-    """Projected keys / values of one cross-attention layer in the layouts csrc/attention.hip wants:
-    K [B, Lk_pad, C] row-major, Vt [C, B*Lk_pad] (transposed, 16-key groups permuted)."""
+    """Projected keys / values of one cross-attention layer in the layouts csrc/xattn.hip wants:
+    K [B, Lk_pad, C] row-major with the 64 dims of every head stored in 16-groups ordered [0-3, 8-11, 4-7, 12-15]
+    (the order the fused kernel's projected query leaves the MFMA accumulators in), Vt [C, B*Lk_pad] (transposed,
+    16-key groups permuted the same way)."""
     __slots__ = ("k", "vt", "lk", "lk_pad", "k2", "vt2", "lk2", "lk2_pad")
 
     def __init__(self):
@@ -108,7 +111,7 @@ def project_kv(ctx, tokens, wk, wv):
     x = torch.zeros(B, n_pad, cx, dtype=ctx.dtype, device=ctx.device)       # plumbing: zero-padded copy
     x[:, :n] = tokens.to(device=ctx.device, dtype=ctx.dtype)
     x2 = x.view(B * n_pad, cx)
-    k = ctx.gemm(x2, wk, descr="to_k")                                          # [B*n_pad, C]
+    k = ctx.gemm(x2, wk, flags=L.GF_VT_PERM, descr="to_k")                      # [B*n_pad, C], head dims permuted
     vt = ctx.gemm(wv, x2, flags=L.GF_VT_PERM, descr="to_v^T")                   # [C, B*n_pad]
     if ctx.record:
         ctx.keep.append(x)
@@ -234,24 +237,25 @@ class IPAttnProcessor2_0(nn.Module):
         C_ = x.shape[1]
         H = attn.heads
         if ln is None:
-            q = ctx.gemm(x, _w(attn.to_q, ctx), descr="cross.to_q")
-        else:       # x is the un-normalised stream; LayerNorm folded into to_q
+            wq, lnq = _w(attn.to_q, ctx), None
+        else:       # x is the un-normalised stream; LayerNorm `ln` folded into to_q inside the fused kernel
             norm = ln
             key = (attn.to_q.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
             fq = _cached(attn, "_imh_ln_q", key, lambda: fold_ln(attn.to_q.weight, norm, ctx))
-            q = ctx.gemm(x, fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps), descr="cross.to_q")
+            wq, lnq = fq[0], (fq[1], fq[2], norm.eps)
         ao = ctx.new(B * L_, C_)
+        # to_q + text attention (+ image-prompt attention + text + scale * ip) in ONE launch (csrc/xattn.hip)
         if kv.k2 is not None:
-            ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
-                          k2=kv.k2, vt2=kv.vt2, Lk2=kv.lk2, Lk2_pad=kv.lk2_pad, ldk2=C_, ldvt2=B * kv.lk2_pad,
-                          scale2=float(self.scale), scale2_tab=scale_tab, step=step if scale_tab is not None else None,
-                          descr="cross.attn+ip")
+            ctx.cross_attention(x, wq, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, B * kv.lk_pad, HEAD_DIM ** -0.5, ln=lnq,
+                                k2=kv.k2, vt2=kv.vt2, Lk2=kv.lk2, Lk2_pad=kv.lk2_pad, ldk2=C_, ldvt2=B * kv.lk2_pad,
+                                scale2=float(self.scale), scale2_tab=scale_tab, step=step if scale_tab is not None else None,
+                                descr="cross.fused+ip")
         else:
-            ctx.attention(q, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, C_, B * kv.lk_pad, C_, HEAD_DIM ** -0.5,
-                          descr="cross.attn")
+            ctx.cross_attention(x, wq, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, B * kv.lk_pad, HEAD_DIM ** -0.5, ln=lnq,
+                                descr="cross.fused")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
                        descr="cross.to_out")
-        ctx.free(q); ctx.free(ao)
+        ctx.free(ao)
         return out
 
     @torch.no_grad()

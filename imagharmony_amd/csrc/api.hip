@@ -94,6 +94,25 @@ static int do_attn(const imh_attn_args* a, hipStream_t s) {
     return attention_launch(p, a->dtype, s);
 }
 
+static int do_xattn(const imh_xattn_args* a, hipStream_t s) {
+    if (!a || !a->X || !a->Wq || !a->K || !a->Vt || !a->O) { set_error("cross_attention: null pointer argument"); return IMH_ERR_ARG; }
+    if ((a->K2 == nullptr) != (a->Vt2 == nullptr)) { set_error("cross_attention: K2 and Vt2 must come together"); return IMH_ERR_ARG; }
+    if ((a->ln_s == nullptr) != (a->ln_c == nullptr) || (a->ln_s && !(a->ln_eps > 0.f))) {
+        set_error("cross_attention: folded LayerNorm needs ln_s, ln_c and ln_eps > 0"); return IMH_ERR_ARG;
+    }
+    if (a->C != a->H * 64) { set_error("cross_attention: C=%d must be H*64 (H=%d)", a->C, a->H); return IMH_ERR_SHAPE; }
+    XAttnParams x;
+    AttnParams& p = x.a;
+    p.Q = nullptr; p.K = a->K; p.Vt = a->Vt; p.K2 = a->K2; p.Vt2 = a->Vt2; p.O = a->O;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.Lk_pad = a->Lk_pad; p.Lk2 = a->Lk2; p.Lk2_pad = a->Lk2_pad;
+    p.ldq = 0; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldk2 = a->ldk2; p.ldvt2 = a->ldvt2; p.ldo = a->ldo;
+    p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step;
+    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
+    x.X = a->X; x.Wq = a->Wq; x.ln_s = a->ln_s; x.ln_c = a->ln_c; x.ln_eps = a->ln_eps;
+    x.C = a->C; x.ldx = a->ldx; x.ldw = a->ldw;
+    return xattn_launch(x, a->dtype, s);
+}
+
 static int do_attn_small(const imh_small_attn_args* a, hipStream_t s) {
     if (!a || !a->Q || !a->K || !a->V || !a->O) { set_error("attention_small: null pointer argument"); return IMH_ERR_ARG; }
     SmallAttnParams p;
@@ -135,6 +154,7 @@ struct imh_op {
         imh_ew_args ew;
         imh_small_attn_args sattn;
         imh_gemm_args gemm2[2];
+        imh_xattn_args xattn;
     } u;
 };
 
@@ -159,6 +179,7 @@ static int run_op(const imh_op& o, hipStream_t s) {
         case IMH_OP_EW: return do_ew(o.ew_op, &o.u.ew, s);
         case IMH_OP_ATTN_SMALL: return do_attn_small(&o.u.sattn, s);
         case IMH_OP_GEMM_DUAL: return do_gemm_dual(&o.u.gemm2[0], &o.u.gemm2[1], s);
+        case IMH_OP_XATTN: return do_xattn(&o.u.xattn, s);
     }
     set_error("plan: unknown op kind %d", o.kind);
     return IMH_ERR_ARG;
@@ -178,6 +199,7 @@ static size_t args_size(int kind) {
         case IMH_OP_EW: return sizeof(imh_ew_args);
         case IMH_OP_ATTN_SMALL: return sizeof(imh_small_attn_args);
         case IMH_OP_GEMM_DUAL: return 2 * sizeof(imh_gemm_args);
+        case IMH_OP_XATTN: return sizeof(imh_xattn_args);
     }
     return 0;
 }
@@ -203,6 +225,8 @@ int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 size_t imh_gemm_workspace_bytes(int M, int N, int splits) { return gemm_workspace_bytes(M, N, splits); }
 
 int imh_attention(const imh_attn_args* a, void* stream) { return do_attn(a, (hipStream_t)stream); }
+
+int imh_cross_attention(const imh_xattn_args* a, void* stream) { return do_xattn(a, (hipStream_t)stream); }
 
 int imh_attention_small(const imh_small_attn_args* a, void* stream) { return do_attn_small(a, (hipStream_t)stream); }
 

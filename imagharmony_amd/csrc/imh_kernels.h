@@ -55,6 +55,19 @@ struct AttnParams {
     unsigned pf_bytes;
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);
+
+// fused to_q (+ folded LayerNorm) + text / image-prompt cross-attention (xattn.hip): `a` carries the key / value caches,
+// O and the shapes (a.Q is unused); the K caches hold the head dims of every 16-group in vt_perm16 order
+struct XAttnParams {
+    AttnParams a;
+    const void* X;        // [B*Lq, ldx] token rows (un-normalised when ln_s != null)
+    const void* Wq;       // [H*64, ldw] to_q weight, [out, in] (pre-scaled by gamma when ln_s != null)
+    const float* ln_s;    // [H*64] sum_k gamma_k Wq[d, k]  or null
+    const float* ln_c;    // [H*64] sum_k beta_k  Wq[d, k]
+    float ln_eps;
+    int C, ldx, ldw;
+};
+int xattn_launch(const XAttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
 extern int g_xcd_mode;
 

@@ -90,4 +90,23 @@ IMH_HD int att_v_off(int lane, int dt, int kt, int s) {   // V^T fragment: d = d
 // O^T accumulator register r of lane half hi holds head-dim index
 IMH_HD int att_o_dim(int dt, int r, int hi) { return dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// ------------------------------------------------- fused cross-attention prologue (xattn.hip)
+// Q^T[64 d, 32 q] per wave = Wq_h[64, C] X[32 q, C]^T on 32x32x16 MFMAs.  Stage = X tile [128 rows][64 k] (each wave
+// fills and reads only its own 32 rows) followed by the Wq tile [64 rows][64 k] (filled by quarters, read by everyone).
+IMH_HD int xq_stage_xrow(int i, int wave, int lane) { return wave * 32 + i * 8 + (lane >> 3); }   // i < 4
+IMH_HD int xq_stage_wrow(int i, int wave, int lane) { return wave * 16 + i * 8 + (lane >> 3); }   // i < 2
+IMH_HD int xq_x_off(int wave, int lane, int ks) {          // B operand: query (lane&31), k = ks*16 + hi*8 ..
+    const int row = wave * 32 + (lane & 31);
+    return tile_off(row, ks * 2 + (lane >> 5), swz_x(row));
+}
+IMH_HD int xq_w_off(int dt, int lane, int ks) {            // A operand: head dim dt*32 + (lane&31), same k
+    const int row = dt * 32 + (lane & 31);
+    return tile_off(row, ks * 2 + (lane >> 5), swz_x(row));
+}
+// accumulator register r of 32x32 block dt becomes slot xq_slot(r) of the Q^T B-operand fragment of QK^T step
+// xq_sd(dt, r): lane half hi then holds head dims {0-3, 8-11} + 4 hi of the step's 16-group, which is the order
+// vt_perm16 stores a K row in -- so the matching K fragment is chunk sd*2 + hi of the permuted row (att_k_off)
+IMH_HD int xq_sd(int dt, int r) { return dt * 2 + (r >> 3); }
+IMH_HD int xq_slot(int r) { return r & 7; }
+
 }  // namespace imh

@@ -1,0 +1,188 @@
+// Fused QKV + image-prompt cross-attention for gfx950 -- the whole attention side of IPAttnProcessor2_0
+// (ip_adapter/attention_processor.py:396-450) in ONE launch:
+//
+//     q   = to_q( LayerNorm(x) )                      (:396; diffusers' norm2 folded in, optional)
+//     O   = softmax(q K^T / 8) V  [ + scale * softmax(q K_ip^T / 8) V_ip ]        (:416-450)
+//
+// K / V of the text tokens and of the image-prompt tokens do not depend on the denoise step (nor on the latent):
+// they arrive as LDS-stageable caches (K row-major, V transposed), projected once per image.  `to_out` (:453) needs
+// every head of a token and stays the next GEMM launch.
+//
+// One workgroup = (batch, head, 128 queries) = 4 waves x 32 queries.
+//   prologue   Q^T[64 d, 32 q] per wave = Wq_h[64, C] . X[32 q, C]^T on v_mfma_f32_32x32x16: the head's weight
+//              slice is the MFMA A operand (shared by the 4 waves through LDS), the wave's own 32 token rows the B
+//              operand (wave-private LDS rows), K loop over C in 64-wide tiles, two LDS-DMA stages.  A query block
+//              is re-read by the H heads (L2 hits), never by redundant arithmetic: the Q tile of a (batch, head,
+//              128-query) item is a 128 x 64 x C GEMM with no overlap between items.
+//   LayerNorm  the token rows' (sum, sum of squares) come out of the same B fragments (v_dot2c under the MFMAs);
+//              q = rstd * (acc - mean * s_d) + c_d with Wq pre-scaled by gamma -- norm2 never materialises.
+//   hand-over  the accumulator layout of a 32x32 MFMA block IS the B-operand layout of the swapped QK^T product
+//              (S^T = K Q^T) once the head dims inside every 16-group are ordered [0-3, 8-11, 4-7, 12-15]; the K
+//              caches are written in that order by their projection GEMM (IMH_GF_VT_PERM), so Q goes from
+//              accumulators to MFMA operands through a cvt only -- no LDS round trip, no global round trip.
+//   attention  the online-softmax key loop shared with attention.hip (imh_attn_core.h): text pass, image-prompt
+//              pass, text + scale * ip formed in registers, one coalesced store.
+// Roofline: the prologue is a GEMM (MFMA-bound, 2*B*L*C^2 FLOP per call); the key loop over 77 + T keys is short.
+#include "imh_attn_core.h"
+
+namespace imh {
+
+constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
+
+template <typename T, int NPASS, bool LNQ>
+__global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XAttnParams xp) {
+    constexpr int NW = 4;
+    typedef typename Vec<T>::v8 v8;
+    static_assert(2 * XQ_STAGE <= ATT_STAGES * 2 * ATT_TILE_BYTES, "the projection stages alias the K / V^T ring");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ATT_STAGES * 2 * ATT_TILE_BYTES];
+    const AttnParams& p = xp.a;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    // same XCD-aware head-major item order as attn_kernel: one XCD sees few heads (their Wq slices, K / V^T) and
+    // streams the query blocks
+    const int gx = (p.Lq + 32 * NW - 1) / (32 * NW);
+    const int items = gx * p.H * p.B;
+    const int per = (items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    const int hb = item / gx, qblk = item - hb * gx;
+    const int b = hb / p.H, h = hb - b * p.H;
+    const int q0 = qblk * (32 * NW);
+
+    // ---- prologue: Q^T = Wq_h X^T ----
+    // staging: 4 LDS-DMA rows-of-8 for the wave's own 32 token rows, 2 for its quarter of the weight tile
+    const unsigned char* xsrc[4];
+    const unsigned char* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = xq_stage_xrow(i, wave, lane);
+        const int ch = stage_chunk_x(row, lane);
+        xsrc[i] = (const unsigned char*)((const T*)xp.X + ((size_t)b * p.Lq + min(q0 + row, p.Lq - 1)) * xp.ldx + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = xq_stage_wrow(i, wave, lane);
+        const int ch = stage_chunk_x(row, lane);
+        wsrc[i] = (const unsigned char*)((const T*)xp.Wq + ((size_t)h * 64 + row) * xp.ldw + ch * 8);
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xs = smem + buf * XQ_STAGE;
+        unsigned char* ws = xs + 128 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(xsrc[i] + (size_t)kt * 128, xs + (wave * 32 + i * 8) * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(wsrc[i] + (size_t)kt * 128, ws + (wave * 16 + i * 8) * 128);
+    };
+    // fragment offsets inside a stage (same row / chunk / swizzle pattern as the K tile of the key loop)
+    int xoff[4], woff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        xoff[ks] = xq_x_off(wave, lane, ks);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) woff[dt][ks] = 128 * 128 + xq_w_off(dt, lane, ks);
+    }
+    f32x16 qa[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qa[dt][r] = 0.f;
+    float st_s = 0.f, st_q = 0.f;
+
+    const int nkt = xp.C / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile kt has landed
+        __builtin_amdgcn_s_barrier();                         // ... everyone's has; tile kt-1 is fully consumed
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* sb = smem + (kt & 1) * XQ_STAGE;
+        v8 xf[4], wf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            xf[ks] = *(const v8*)(sb + xoff[ks]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) wf[dt][ks] = *(const v8*)(sb + woff[dt][ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
+        if constexpr (LNQ) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave is done with the projection stages: the K / V^T ring may reuse them
+
+    // ---- accumulators -> Q^T B-operand fragments of the key loop.  MFMA step sd = 2*dt + u contracts the 16 head dims
+    //      [32 dt + 16 u, +16); lane half hi supplies accumulator registers 8u .. 8u+7 of block dt, i.e. dims
+    //      {0-3, 8-11} + 4 hi of that group -- the order the permuted K cache stores them in. ----
+    v8 qf[4];
+    {
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (LNQ) {
+            const float invc = 1.0f / (float)xp.C;
+            mean = xor32_sum(st_s) * invc;                     // the row's other k-slices live in lane ^ 32
+            rstd = rsqrtf(fmaxf(xor32_sum(st_q) * invc - mean * mean, 0.f) + xp.ln_eps);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = qa[dt][rg * 4 + e];
+                if constexpr (LNQ) {
+                    const int d = h * 64 + att_o_dim(dt, rg * 4, hi);          // 4 consecutive head dims
+                    const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * s4[e]) + c4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[xq_sd(dt, rg * 4 + e)][xq_slot(rg * 4 + e)] = from_f32<T>(v[e]);
+            }
+    }
+
+    f32x16 fin[2];
+    attn_core<T, NW, NPASS>(p, smem, qf, b, h, wave, lane, item, fin);
+    attn_store<T, NW>(p, smem, fin, b, h, q0, wave, lane);
+    tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+}
+
+int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
+    const AttnParams& p = xp.a;
+    if (p.Lk <= 0 || p.Lk_pad % ATT_KV != 0 || p.Lk_pad < p.Lk) {
+        set_error("cross_attention: Lk=%d Lk_pad=%d (pad must be a multiple of 64 and >= Lk)", p.Lk, p.Lk_pad);
+        return IMH_ERR_SHAPE;
+    }
+    if (p.K2 && (p.Lk2 <= 0 || p.Lk2_pad % ATT_KV != 0 || p.Lk2_pad < p.Lk2)) {
+        set_error("cross_attention: Lk2=%d Lk2_pad=%d invalid", p.Lk2, p.Lk2_pad);
+        return IMH_ERR_SHAPE;
+    }
+    if (xp.C <= 0 || xp.C % 64) { set_error("cross_attention: C=%d must be a positive multiple of 64", xp.C); return IMH_ERR_SHAPE; }
+    if ((xp.ldx & 7) || (xp.ldw & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 7) || (p.K2 && ((p.ldk2 & 7) || (p.ldvt2 & 7)))) {
+        set_error("cross_attention: leading dimensions must be multiples of 8 elements");
+        return IMH_ERR_SHAPE;
+    }
+    if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("cross_attention: empty problem"); return IMH_ERR_SHAPE; }
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("cross_attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    const int items = ((p.Lq + 127) / 128) * p.H * p.B;
+    dim3 grid(8 * ((items + 7) / 8));
+    const bool ln = xp.ln_s != nullptr;
+#define IMH_XA(TT) do { \
+        if (p.K2) { if (ln) hipLaunchKernelGGL((xattn_kernel<TT, 2, true>), grid, dim3(256), 0, stream, xp); \
+                    else hipLaunchKernelGGL((xattn_kernel<TT, 2, false>), grid, dim3(256), 0, stream, xp); } \
+        else { if (ln) hipLaunchKernelGGL((xattn_kernel<TT, 1, true>), grid, dim3(256), 0, stream, xp); \
+               else hipLaunchKernelGGL((xattn_kernel<TT, 1, false>), grid, dim3(256), 0, stream, xp); } } while (0)
+    if (dtype == IMH_DT_BF16) IMH_XA(bf16_t);
+    else IMH_XA(f16_t);
+#undef IMH_XA
+    return check_launch("xattn_kernel");
+}
+
+}  // namespace imh

@@ -121,7 +121,7 @@ class Ctx:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(k for k in keep if k is not None)
             self.tags.append((self.tag, kind, descr, flops, nbytes, shape, epi))
-            self._ops.append((kind, args, self._cold(keep) if kind == L.OP_GEMM else []))
+            self._ops.append((kind, args, self._cold(keep) if kind in (L.OP_GEMM, L.OP_XATTN) else []))
             return
         s = self.stream()
         if kind == L.OP_GEMM:
@@ -134,6 +134,8 @@ class Ctx:
             rc = self.lib.imh_layernorm(C.byref(args), s)
         elif kind == L.OP_ATTN_SMALL:
             rc = self.lib.imh_attention_small(C.byref(args), s)
+        elif kind == L.OP_XATTN:
+            rc = self.lib.imh_cross_attention(C.byref(args), s)
         else:
             rc = self.lib.imh_elementwise(ew_op, C.byref(args), s)
         L.check(rc, descr or f"op kind {kind}")
@@ -272,6 +274,34 @@ class Ctx:
         self._emit(L.OP_ATTN, a, descr=descr, flops=fl, nbytes=by, keep=(q, k, vt, out, k2, vt2, scale2_tab, step))
         return out
 
+    def cross_attention(self, x, wq, k, vt, out, B, H, Lq, Lk, Lk_pad, ldk, ldvt, scale, ln=None,
+                        k2=None, vt2=None, Lk2=0, Lk2_pad=0, ldk2=0, ldvt2=0, scale2=0.0, scale2_tab=None, step=None,
+                        descr="cross.fused"):
+        """out[B*Lq, C] = attention(to_q(LN?(x)), K, V) (+ scale2 * attention(., K2, V2)) in one launch
+        (csrc/xattn.hip).  x [B*Lq, C]; wq [C, C]; k / k2 caches with head dims in vt_perm16 order (GF_VT_PERM);
+        ln = (s, c, eps): x is un-normalised and wq pre-scaled by gamma."""
+        self._chk(x, descr + ".x"); self._chk(wq, descr + ".wq")
+        C_ = H * 64
+        if x.shape[-1] != C_ or tuple(wq.shape) != (C_, C_) or x.stride(-1) != 1 or wq.stride(-1) != 1:
+            raise L.ImhError(f"{descr}: x [.., {C_}] / wq [{C_}, {C_}] expected, got {tuple(x.shape)} / {tuple(wq.shape)}")
+        a = L.XAttnArgs()
+        a.X, a.Wq, a.K, a.Vt, a.O = x.data_ptr(), wq.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+        a.K2, a.Vt2 = self._p(k2), self._p(vt2)
+        if ln is not None:
+            a.ln_s, a.ln_c, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+        a.B, a.H, a.Lq, a.C = B, H, Lq, C_
+        a.Lk, a.Lk_pad, a.Lk2, a.Lk2_pad = Lk, Lk_pad, Lk2, Lk2_pad
+        a.ldx, a.ldw, a.ldk, a.ldvt, a.ldk2, a.ldvt2, a.ldo = x.stride(0), wq.stride(0), ldk, ldvt, ldk2, ldvt2, out.stride(0)
+        a.scale, a.scale2, a.dtype = scale, scale2, self.dt
+        a.scale2_tab, a.step = self._p(scale2_tab), self._p(step)
+        es = x.element_size()
+        M = B * Lq
+        fl = 2.0 * M * C_ * C_ + 4.0 * B * H * Lq * (Lk + Lk2) * 64
+        by = es * (2 * M * C_ + C_ * C_ + 2 * B * (Lk + Lk2) * C_)
+        self._emit(L.OP_XATTN, a, descr=descr, flops=fl, nbytes=by,
+                   keep=(x, wq, k, vt, out, k2, vt2, scale2_tab, step) + tuple((ln or ())[:2]))
+        return out
+
     def attention_small(self, q, k, v, B, H, Lq, Lk, dq, dv, scale, out=None, descr="attention_small"):
         """q [B*Lq, H*dq], k [B*Lk, H*dq], v [B*Lk, H*dv] row-major (any row stride) -> [B*Lq, H*dv]"""
         if out is None:
@@ -359,7 +389,7 @@ class Ctx:
         if self._pf_done or not self.record:
             return
         self._pf_done = True
-        can = (L.OP_GEMM, L.OP_ATTN, L.OP_LAYERNORM, L.OP_GROUPNORM, L.OP_GEMM_DUAL)
+        can = (L.OP_GEMM, L.OP_ATTN, L.OP_LAYERNORM, L.OP_GROUPNORM, L.OP_GEMM_DUAL, L.OP_XATTN)
         taken = set()
         for j, (kind, args, cold) in enumerate(self._ops):
             for (ptr, nb) in cold:

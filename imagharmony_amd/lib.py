@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so"
 ABI_VERSION = 3
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
-OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL = 0, 1, 2, 3, 4, 5, 6
+OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
 EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX = range(10)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
@@ -34,6 +34,16 @@ class AttnArgs(C.Structure):
                 ("B", _i32), ("H", _i32), ("Lq", _i32), ("Lk", _i32), ("Lk_pad", _i32), ("Lk2", _i32),
                 ("Lk2_pad", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldvt", _i32), ("ldk2", _i32), ("ldvt2", _i32), ("ldo", _i32),
+                ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32),
+                ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
+
+
+class XAttnArgs(C.Structure):
+    _fields_ = [("X", _vp), ("Wq", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
+                ("K", _vp), ("Vt", _vp), ("K2", _vp), ("Vt2", _vp), ("O", _vp),
+                ("B", _i32), ("H", _i32), ("Lq", _i32), ("C", _i32), ("Lk", _i32), ("Lk_pad", _i32), ("Lk2", _i32),
+                ("Lk2_pad", _i32),
+                ("ldx", _i32), ("ldw", _i32), ("ldk", _i32), ("ldvt", _i32), ("ldk2", _i32), ("ldvt2", _i32), ("ldo", _i32),
                 ("scale", _f32), ("scale2", _f32), ("scale2_tab", _vp), ("step", _vp), ("dtype", _i32),
                 ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
@@ -68,6 +78,7 @@ SYMBOLS = [
                                        C.POINTER(C.c_int)]),
     ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("imh_attention", C.c_int, [C.POINTER(AttnArgs), _vp]),
+    ("imh_cross_attention", C.c_int, [C.POINTER(XAttnArgs), _vp]),
     ("imh_attention_small", C.c_int, [C.POINTER(SmallAttnArgs), _vp]),
     ("imh_groupnorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_groupnorm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -145,6 +145,45 @@ typedef struct imh_attn_args {
 
 int imh_attention(const imh_attn_args* a, void* stream);
 
+/* ---- fused QKV + image-prompt cross-attention ---------------------------------------------
+ * The attention side of IPAttnProcessor2_0.__call__ (ip_adapter/attention_processor.py:396-450) in one launch:
+ *   q = attn.to_q(LN(x))                      (:396; the BasicTransformerBlock.norm2 in front of it folded in, optional)
+ *   O = softmax(q K^T * scale) V  (+ scale2 * softmax(q K2^T * scale) V2)          (:416-425, :432-442, :450)
+ * K / Vt (text tokens, attn.to_k / to_v, :410-411) and K2 / Vt2 (image-prompt tokens, to_k_ip / to_v_ip, :432-433)
+ * are step-invariant caches in imh_attention's layouts, EXCEPT that K and K2 store the 64 dims of every head with
+ * each 16-group ordered [0-3, 8-11, 4-7, 12-15] (write them with IMH_GF_VT_PERM): the projected query leaves the
+ * MFMA accumulators in exactly that order and becomes the QK^T operand without touching LDS or memory.
+ * attn.to_out (:453) needs all heads of a token and stays a following imh_gemm.
+ *   X  : [B*Lq, ldx] token rows, C = H*64 columns; un-normalised when ln_s != NULL
+ *   Wq : [H*64, ldw] = attn.to_q.weight ([out, in]); with ln_s != NULL pre-scaled by the LayerNorm gamma,
+ *        ln_s[d] = sum_k gamma_k Wq[d,k], ln_c[d] = sum_k beta_k Wq[d,k] (fp32) as for IMH_GF_LN_ROW
+ */
+typedef struct imh_xattn_args {
+    const void* X;
+    const void* Wq;
+    const float* ln_s;
+    const float* ln_c;
+    float ln_eps;
+    const void* K;
+    const void* Vt;
+    const void* K2;
+    const void* Vt2;
+    void* O;
+    int32_t B, H, Lq, C;
+    int32_t Lk, Lk_pad;
+    int32_t Lk2, Lk2_pad;
+    int32_t ldx, ldw, ldk, ldvt, ldk2, ldvt2, ldo;
+    float scale;
+    float scale2;
+    const float* scale2_tab; /* optional per-step table of IP scales (custom_pipelines.py:326-329), indexed by *step */
+    const int32_t* step;
+    int32_t dtype;
+    const void* pf_ptr;      /* tail prefetch of the next launch's weights (cache hint) */
+    uint32_t pf_bytes;
+} imh_xattn_args;
+
+int imh_cross_attention(const imh_xattn_args* a, void* stream);
+
 /* small generic attention (arbitrary head dims, short sequences), row-major Q/K/V, one softmax:
  * HarmonyAttention's Cross_Attention (ip_adapter/attention_processor.py:35-56, head_dim 40 / value_dim 64)
  * and the Resampler's PerceiverAttention core (ip_adapter/resampler.py:66-76).  Once per image. */
@@ -220,7 +259,7 @@ int imh_elementwise(int op, const imh_ew_args* a, void* stream);
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */
 enum imh_op_kind { IMH_OP_GEMM = 0, IMH_OP_ATTN = 1, IMH_OP_GROUPNORM = 2, IMH_OP_LAYERNORM = 3, IMH_OP_EW = 4,
-                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6 };
+                   IMH_OP_ATTN_SMALL = 5, IMH_OP_GEMM_DUAL = 6, IMH_OP_XATTN = 7 };
 
 typedef struct imh_plan imh_plan;
 

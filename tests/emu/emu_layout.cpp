@@ -184,6 +184,75 @@ static int test_attention(int Lk_valid, int Lk_pad) {
     return bad;
 }
 
+// fused cross-attention prologue (xattn.hip): project Q^T = Wq_h X^T through the kernel's staging / fragment maps,
+// hand the accumulators over as QK^T B operands, and form S^T against a K tile stored in vt_perm16 order.
+static int test_xattn_handover(int C) {
+    const int D = 64, NQ = 128, NK = 64;
+    std::vector<float> X(NQ * C), Wq(D * C), Kx(NK * D), KP(NK * D), R(NQ * NK), S(NQ * NK, NAN);
+    for (auto& v : X) v = frand() * 0.5f;
+    for (auto& v : Wq) v = frand() * 0.5f;
+    for (auto& v : Kx) v = frand();
+    for (int k = 0; k < NK; ++k) for (int d = 0; d < D; ++d) KP[k * D + ((d & ~15) | vt_perm16(d & 15))] = Kx[k * D + d];
+    for (int q = 0; q < NQ; ++q) for (int k = 0; k < NK; ++k) {
+        double a = 0;
+        for (int d = 0; d < D; ++d) { double qd = 0; for (int c = 0; c < C; ++c) qd += (double)X[q * C + c] * Wq[d * C + c]; a += qd * Kx[k * D + d]; }
+        R[q * NK + k] = (float)a;
+    }
+    std::vector<std::vector<float>> qa(4 * 64, std::vector<float>(32, 0.f));
+    for (int kt = 0; kt < C / 64; ++kt) {
+        Lds xs(128 * 128), ws(64 * 128);
+        for (int wave = 0; wave < 4; ++wave) for (int lane = 0; lane < 64; ++lane) {
+            for (int i = 0; i < 4; ++i) {
+                const int row = xq_stage_xrow(i, wave, lane), ch = stage_chunk_x(row, lane);
+                float* d = xs.at((wave * 32 + i * 8) * 128 + lane * 16);
+                for (int e = 0; e < 8; ++e) d[e] = X[row * C + kt * 64 + ch * 8 + e];
+            }
+            for (int i = 0; i < 2; ++i) {
+                const int row = xq_stage_wrow(i, wave, lane), ch = stage_chunk_x(row, lane);
+                float* d = ws.at((wave * 16 + i * 8) * 128 + lane * 16);
+                for (int e = 0; e < 8; ++e) d[e] = Wq[row * C + kt * 64 + ch * 8 + e];
+            }
+        }
+        for (int wave = 0; wave < 4; ++wave) for (int ks = 0; ks < 4; ++ks) for (int dt = 0; dt < 2; ++dt) {
+            float a[64][8], b[64][8], c16[64][16];
+            for (int lane = 0; lane < 64; ++lane) {
+                const float* xf = xs.at(xq_x_off(wave, lane, ks));
+                const float* wf = ws.at(xq_w_off(dt, lane, ks));
+                for (int e = 0; e < 8; ++e) { a[lane][e] = wf[e]; b[lane][e] = xf[e]; }
+                for (int r = 0; r < 16; ++r) c16[lane][r] = qa[wave * 64 + lane][dt * 16 + r];
+            }
+            mfma32(a, b, c16);
+            for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 16; ++r) qa[wave * 64 + lane][dt * 16 + r] = c16[lane][r];
+        }
+    }
+    // K tile staged exactly as attn_core stages it (from the PERMUTED cache)
+    Lds ks(64 * 128);
+    for (int w2 = 0; w2 < 4; ++w2) for (int lane = 0; lane < 64; ++lane) for (int i = 0; i < 2; ++i) {
+        const int row = stage_row(i, w2, lane), ch = stage_chunk_x(row, lane);
+        float* dk = ks.at(stage_lds_off(i, w2) + lane * 16);
+        for (int e = 0; e < 8; ++e) dk[e] = KP[row * D + ch * 8 + e];
+    }
+    for (int wave = 0; wave < 4; ++wave) {
+        float qf[4][64][8];
+        for (int lane = 0; lane < 64; ++lane) for (int dt = 0; dt < 2; ++dt) for (int r = 0; r < 16; ++r)
+            qf[xq_sd(dt, r)][lane][xq_slot(r)] = qa[wave * 64 + lane][dt * 16 + r];
+        for (int kt = 0; kt < 2; ++kt) {
+            float st[64][16] = {};
+            for (int sd = 0; sd < 4; ++sd) {
+                float a[64][8];
+                for (int lane = 0; lane < 64; ++lane) { const float* kf = ks.at(att_k_off(lane, kt, sd)); for (int e = 0; e < 8; ++e) a[lane][e] = kf[e]; }
+                mfma32(a, qf[sd], st);
+            }
+            for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 16; ++r)
+                S[(wave * 32 + (lane & 31)) * NK + kt * 32 + st_key(r, lane >> 5)] = st[lane][r];
+        }
+    }
+    int bad = 0;
+    for (int i = 0; i < NQ * NK; ++i) if (!(std::fabs((double)S[i] - R[i]) <= 1e-3 * (1.0 + std::fabs((double)R[i])))) ++bad;
+    printf("xattn hand-over C=%d: %s (%d mismatches)\n", C, bad ? "FAIL" : "ok", bad);
+    return bad;
+}
+
 int main() {
     srand(1234);
     int bad = 0;
@@ -195,5 +264,7 @@ int main() {
     bad += test_attention(77, 128);
     bad += test_attention(4, 64);
     bad += test_attention(33, 64);
+    bad += test_xattn_handover(128);
+    bad += test_xattn_handover(320);
     return bad ? 1 : 0;
 }

@@ -194,6 +194,51 @@ def test_attention_cross_ip(L, dtype, B, H, Lq, nt, nip):
     assert_close(out.view(B, Lq, C_), ref, dtype, "cross attention", k=6.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,nt,nip,ln", [(2, 2, 256, 77, 4, True), (1, 20, 128, 77, 16, True), (2, 5, 100, 77, 32, False),
+                                               (1, 10, 192, 130, 0, True), (2, 20, 1024, 77, 4, True), (2, 10, 4096, 77, 0, False)])
+def test_fused_cross_attention(L, dtype, B, H, Lq, nt, nip, ln):
+    """csrc/xattn.hip -- to_q (+ folded LayerNorm) + text attention (+ image-prompt attention, text + s * ip) in ONE
+    launch against the same ops in fp32 torch: q = LN(x) Wq^T rounded to the compute dtype (as attn.to_q does), then
+    SDPA per key set.  K caches carry the head dims in the permuted order the kernel's hand-over expects."""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    C_ = H * 64
+    x = (rnd(B * Lq, C_, dtype=dtype, seed=1) * 1.3 + (0.7 if ln else 0.0)).contiguous()
+    wq = rnd(C_, C_, dtype=torch.float32, seed=6, scale=C_ ** -0.5)
+    k, v = rnd(B, nt, C_, dtype=dtype, seed=2), rnd(B, nt, C_, dtype=dtype, seed=3)
+    pad = lambda n: (n + 63) // 64 * 64
+
+    def make_k(kk, n_pad):            # [B, n, C] -> zero-padded, every 16-group of head dims stored as [0-3, 8-11, 4-7, 12-15]
+        kp = torch.zeros(B, n_pad, C_, dtype=dtype, device=DEV)
+        kp[:, :kk.shape[1]] = kk
+        return kp.view(B, n_pad, C_ // 16, 4, 4)[:, :, :, [0, 2, 1, 3], :].reshape(B, n_pad, C_).contiguous()
+
+    if ln:
+        norm = torch.nn.LayerNorm(C_, eps=1e-5)
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.2 * torch.randn(C_, generator=torch.Generator().manual_seed(3)))
+            norm.bias.copy_(0.3 * torch.randn(C_, generator=torch.Generator().manual_seed(4)))
+        wg, s_, c_ = fold_ln(wq, norm, ctx)
+        lnq = (s_, c_, 1e-5)
+        xn = F.layer_norm(x.float(), (C_,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
+        q_ref = (xn @ wq.to(DEV).t()).to(dtype)
+    else:
+        wg, lnq = wq.to(DEV, dtype), None
+        q_ref = (x.float() @ wg.float().t()).to(dtype)
+    ref = sdpa_ref(q_ref.view(B, Lq, C_), k, v, H)
+    kw = {}
+    if nip:
+        k2, v2 = rnd(B, nip, C_, dtype=dtype, seed=4), rnd(B, nip, C_, dtype=dtype, seed=5)
+        kw = dict(k2=make_k(k2, pad(nip)), vt2=make_vt(v2, pad(nip)), Lk2=nip, Lk2_pad=pad(nip), ldk2=C_, ldvt2=B * pad(nip), scale2=0.7)
+        ref = ref + 0.7 * sdpa_ref(q_ref.view(B, Lq, C_), k2, v2, H)
+    out = ctx.new(B * Lq, C_)
+    ctx.cross_attention(x, wg, make_k(k, pad(nt)), make_vt(v, pad(nt)), out, B, H, Lq, nt, pad(nt), C_, B * pad(nt), 0.125,
+                        ln=lnq, **kw)
+    # the reference rounds q once (bf16 / fp16) exactly like the kernel's hand-over; k = 8 ulps of the output scale
+    assert_close(out.view(B, Lq, C_), ref, dtype, f"fused cross attention B={B} H={H} Lq={Lq} nt={nt} nip={nip} ln={ln}", k=8.0)
+
+
 def test_attention_spiked_scores(L):
     """forces the online-softmax rescale path: one key dominates late in the sequence"""
     dtype = torch.bfloat16

@@ -30,7 +30,7 @@ def test_ctypes_structs_match_header_field_order():
     hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
     for cname, struct in (("imh_gemm_args", lib.GemmArgs), ("imh_attn_args", lib.AttnArgs),
                           ("imh_norm_args", lib.NormArgs), ("imh_ew_args", lib.EwArgs),
-                          ("imh_small_attn_args", lib.SmallAttnArgs)):
+                          ("imh_small_attn_args", lib.SmallAttnArgs), ("imh_xattn_args", lib.XAttnArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -117,7 +117,10 @@ def test_unet_recording_dry_run_tiny():
     n_blocks = 2 + 4 + 2 + 6 + 3
     assert n > 12 * n_blocks
     kinds = [k for _, k, *_ in ctx.tags]
-    assert kinds.count(1) == n_prep * 0 + 2 * n_blocks          # one self + one cross attention per block
+    from imagharmony_amd import lib as L
+    assert kinds.count(L.OP_ATTN) == n_blocks                   # one self-attention launch per block ...
+    assert kinds.count(L.OP_XATTN) == n_blocks                  # ... and one fused to_q + cross-attention launch
+    assert kinds.count(L.OP_LAYERNORM) == 0                     # norm1/2/3 are folded into their consumer GEMMs
     with pytest.raises(Exception):
         ctx.run()
 
