@@ -248,7 +248,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
 }
 
 template <typename T, int BM, int BN, bool CONV, int LN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+IMH_KERNEL __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     gemm_body<T, BM, BN, CONV, LN>(p, blockIdx.x, blockIdx.y);
 }
 
@@ -257,14 +257,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // lets the two sub-chip-sized grids fill the machine together.
 // LNP: false = plain problems; true = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both).
 template <typename T, int BM, int BN, bool LNP>
-__global__ __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
+IMH_KERNEL __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
     if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP ? 1 : 0>(a, blockIdx.x, 0);
     else gemm_body<T, BM, BN, false, LNP ? 2 : 0>(b, blockIdx.x - grid_a, 0);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+IMH_KERNEL __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
     const int groups_n = (p.N + 15) / 16;
     const size_t total = (size_t)p.M * groups_n;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {

@@ -27,6 +27,25 @@ template <typename T> struct Vec;
 template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
 template <> struct Vec<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };
 
+// Kernel qualifier of the gemm.hip kernels (the ones that carry the folded-LayerNorm epilogue): packed-fp32 VALU code generation OFF (scalar v_fma_f32 instead of
+// compiler-formed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Measured on MI355X (tools/pk_fma_probe.py reproduces it
+// against a build without this attribute): with two or more workgroups resident per CU and the epilogue's operands
+// arriving from cold memory, SLP-formed `v_pk_fma_f32 ... op_sel:[0,1,0]` (the LOW lane reading the ODD register of a
+// pair) returned wrong low halves for one 16-lane row at a time -- 300-800 wrong outputs per 8192 x 1280 x 640
+// folded-LayerNorm GEMM, non-deterministic; gone with scalar fp32 math, with one workgroup per CU, or with this attribute
+// (0 wrong in 108 cold runs).  The epilogues are not VALU-bound, so scalar fp32 costs nothing measurable.
+// gemm_ring.hip / norm.hip / elementwise.hip contain no odd-register low-lane selects (checked in the ISA) and stay as they are (the
+// attribute would also stop hipcc from inlining the HIP headers' own device functions there).  The attention kernels use
+// packed math deliberately (float2 builtins with broadcast operands); the one place where the SLP vectoriser formed the
+// same pattern there (the folded LayerNorm of the projected query) is written with fma_nopk().
+#define IMH_KERNEL __attribute__((target("no-packed-fp32-ops"))) __global__
+// a*b + c as a scalar v_fma_f32 the SLP vectoriser cannot pair into v_pk_fma_f32
+__device__ __forceinline__ float fma_nopk(float a, float b, float c) {
+    float r = __builtin_fmaf(a, b, c);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // ---- MFMA wrappers (cdna_hip_programming.md section 3) ----
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
                     const int d = h * 64 + att_o_dim(dt, rg * 4, hi);          // 4 consecutive head dims
                     const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * s4[e]) + c4[e];
+                    for (int e = 0; e < 4; ++e) v[e] = fma_nopk(rstd, fma_nopk(-mean, s4[e], v[e]), c4[e]);   // scalar on purpose (IMH_KERNEL note)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qf[xq_sd(dt, rg * 4 + e)][xq_slot(rg * 4 + e)] = from_f32<T>(v[e]);

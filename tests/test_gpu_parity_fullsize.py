@@ -170,14 +170,22 @@ def _rnd(shape, dtype, seed, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
 
 
-def _close(y, ref, dtype, what):
+def _rand_norm(K):
+    norm = torch.nn.LayerNorm(K, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3)))
+        norm.bias.copy_(0.3 * torch.randn(K, generator=torch.Generator().manual_seed(4)))
+    return norm
+
+
+def _close(y, ref, dtype, what, k=4.0):
     y, ref = y.float(), ref.float()
     scale = ref.abs().max().item() + 1e-6
     err = (y - ref).abs().max().item()
     rms = ((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12)).item()
     assert math.isfinite(err), f"{what}: non-finite"
     # same bound as tests/test_gpu_ops.py: a few output ulps of the result scale, 2 ulp rel-rms
-    assert err <= 4.0 * EPS[dtype] * scale and rms <= 2 * EPS[dtype], f"{what}: max err {err:.3e} (scale {scale:.3e}) rel-rms {rms:.3e}"
+    assert err <= k * EPS[dtype] * scale and rms <= 2 * EPS[dtype], f"{what}: max err {err:.3e} (scale {scale:.3e}) rel-rms {rms:.3e}"
 
 
 def _ref_epilogue(acc, epi, bias, residual, rowadd, L):
@@ -204,6 +212,7 @@ def _ref_epilogue(acc, epi, bias, residual, rowadd, L):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
     from imagharmony_amd import lib as L
+    from imagharmony_amd.attention_processor import fold_ln
     from imagharmony_amd.ctx import Ctx
     ctx = Ctx(DEV, dtype)
     ops = _ops()
@@ -216,9 +225,20 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
             wqk = _rnd((N1, K1), dtype, 2, K1 ** -0.5)
             wv = _rnd((M2, K2), dtype, 3, K2 ** -0.5)
             assert N2 == M1 and K1 == K2
-            qk, vt = ctx.gemm_dual(dict(x=x, w=wqk, flags=f1), dict(x=wv, w=x, flags=f2), cfg=epi["cfg"], descr=descr)
-            _close(qk, x.float() @ wqk.float().t(), dtype, f"{descr} [Q|K] {epi}")
-            _close(vt, _ref_epilogue(wv.float() @ x.float().t(), dict(flags=f2), None, None, None, L), dtype, f"{descr} V^T {epi}")
+            if f1 & L.GF_LN_ROW:      # the forward's launch: norm1 folded into both problems (x un-normalised, mean != 0)
+                x = (x.float() * 1.5 + 2.0).to(dtype)
+                norm = _rand_norm(K1)
+                wqk_g, s1, c1 = fold_ln(wqk.float(), norm, ctx)
+                wv_g, s2, c2 = fold_ln(wv.float(), norm, ctx)
+                qk, vt = ctx.gemm_dual(dict(x=x, w=wqk_g, flags=f1, ln=(s1, c1, 1e-5)), dict(x=wv_g, w=x, flags=f2, ln=(s2, c2, 1e-5)),
+                                       cfg=epi["cfg"], descr=descr)
+                xn = F.layer_norm(x.float(), (K1,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
+            else:
+                qk, vt = ctx.gemm_dual(dict(x=x, w=wqk, flags=f1), dict(x=wv, w=x, flags=f2), cfg=epi["cfg"], descr=descr)
+                xn = x.float()
+            _close(qk, xn @ wqk.float().t(), dtype, f"{descr} [Q|K] {epi}", k=6.0 if f1 & L.GF_LN_ROW else 4.0)
+            _close(vt, _ref_epilogue(wv.float() @ xn.t(), dict(flags=f2), None, None, None, L), dtype, f"{descr} V^T {epi}",
+                   k=6.0 if f1 & L.GF_LN_ROW else 4.0)
             variants.add(("dual",) + tuple(epi["cfg"]))
             ctx.free(qk); ctx.free(vt)
             n_checked += 1
@@ -247,10 +267,20 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
             _close(y.view(M, N), ref, dtype, f"{descr} {shape} {epi}")
         else:
             x = _rnd((M, K), dtype, 1)
-            y = ctx.gemm(x, w, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
-                         flags=epi["flags"] & ~(L.GF_LN_ROW | L.GF_LN_COL), cfg=(bm, bn, sp), descr=descr)
-            ref = _ref_epilogue(x.float() @ w.float().t(), epi, bias, residual, rowadd, L)
-            _close(y, ref, dtype, f"{descr} {shape} {epi}")
+            if epi["flags"] & L.GF_LN_ROW:      # LayerNorm folded in (norm3 -> GEGLU, ...): test the kernel the forward runs
+                x = (x.float() * 1.5 + 2.0).to(dtype)
+                norm = _rand_norm(K)
+                wg, s_, c_ = fold_ln(w.float(), norm, ctx)
+                y = ctx.gemm(x, wg, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
+                             flags=epi["flags"], ln=(s_, c_, 1e-5), cfg=(bm, bn, sp), descr=descr)
+                xn = F.layer_norm(x.float(), (K,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
+                _close(y, _ref_epilogue(xn @ w.float().t(), epi, bias, residual, rowadd, L), dtype, f"{descr} {shape} {epi}", k=6.0)
+            else:
+                assert not epi["flags"] & L.GF_LN_COL
+                y = ctx.gemm(x, w, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
+                             flags=epi["flags"], cfg=(bm, bn, sp), descr=descr)
+                ref = _ref_epilogue(x.float() @ w.float().t(), epi, bias, residual, rowadd, L)
+                _close(y, ref, dtype, f"{descr} {shape} {epi}")
         ctx.free(y)
         n_checked += 1
         del x, w
