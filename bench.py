@@ -144,6 +144,47 @@ def cpu_baseline(res, ip_tokens, denoise_steps):
     return out
 
 
+def resampler_extra(device, dtype):
+    """ms per call of the IP-Adapter-Plus-XL Resampler (ip_adapter/resampler.py:81-158 at the ip_adapter.py:392-403 config:
+    dim 1280, depth 4, 20 heads x 64, 16 queries, 257 CLIP patch tokens -> [B, 16, 2048]) on the HIP kernels, eager and
+    replayed from a captured graph, against the weight-read bound (every weight byte once at 6.3 TB/s)."""
+    from imagharmony_amd.modules import Resampler
+    m = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, embedding_dim=1280, output_dim=2048, ff_mult=4)
+    m = m.to(device, dtype).eval()
+    wbytes = sum(p.numel() * p.element_size() for p in m.parameters())
+    out = {"weight_bytes": wbytes, "weight_read_bound_us": wbytes / 6.3e12 * 1e6, "ms_per_call": {}}
+    for B in (1, 4):
+        x = torch.randn(B, 257, 1280, generator=torch.Generator("cpu").manual_seed(5)).to(device, dtype)
+        for _ in range(3):
+            y = m(x)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            y = m(x)
+        torch.cuda.synchronize(device)
+        eager = (time.perf_counter() - t0) / 10 * 1e3
+        s = torch.cuda.Stream(device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            m(x)
+            torch.cuda.synchronize(device)
+            with torch.cuda.graph(g, stream=s):
+                yg = m(x)
+        torch.cuda.current_stream(device).wait_stream(s)
+        g.replay(); torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize(device)
+        out["ms_per_call"][f"B={B}"] = {"eager": eager, "graph_replay": (time.perf_counter() - t0) / 20 * 1e3,
+                                        "outputs_finite": bool(torch.isfinite(yg.float()).all().item()),
+                                        "replay_equals_eager": bool(torch.equal(yg, y))}
+    out["note"] = ("once per image (twice with the unconditional branch, ip_adapter.py:413-416); ~45 launches of 1-16-row GEMMs, "
+                   "LayerNorms and the LDS-resident 16 x 273 latent cross-attention: launch-latency-bound, not on the per-step path")
+    return out
+
+
 def _self_launch(n, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RCCL) ourselves through
     torch.distributed.run; rank 0's single JSON line goes to our stdout.  Returns the launcher's exit code."""
@@ -382,6 +423,11 @@ def main():
                 del vae
             except Exception as e:      # noqa: BLE001
                 res["vae_decode"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and a.stacked > 1:        # same "extras" switch: SURVEY.md 8(a5), once per image, never in `value`
+            try:
+                res["resampler"] = resampler_extra(device, dtype)
+            except Exception as e:      # noqa: BLE001
+                res["resampler"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_res, a.ip_tokens, a.denoise_steps)

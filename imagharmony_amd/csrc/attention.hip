@@ -125,9 +125,98 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p
     }
 }
 
+// ---- the same op with the head's keys and values resident in LDS (the Resampler / HarmonyAttention shapes:
+// 8-16 queries x 77-273 keys, head dims 40-64).  One workgroup per (batch, head); K is staged TRANSPOSED ([dq][LkP], so a
+// wave's lanes = consecutive keys read consecutive LDS addresses), V as is ([Lk][dv], lanes = consecutive head dims);
+// every wave then owns every 4th query: scores (lane = key), fp32 softmax across the wave, P V (lane = head dim).
+// K and V are read from global memory once per (batch, head) with 16-B loads instead of once per query with
+// 2-B loads (attn_small_kernel: 16 x 35 KB uncoalesced per head at the PlusXL Resampler shape).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_small_lds_kernel(const SmallAttnParams p, const int LkP) {
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    T* kt = (T*)smraw;                                   // [dq][LkP]
+    T* vs = kt + (size_t)p.dq * LkP;                     // [Lk][dv]
+    float* pr = (float*)(vs + (size_t)p.Lk * p.dv);      // [4][LkP] scores / probabilities of the wave's current query
+    float* qr = pr + 4 * LkP;                            // [4][dq]  the wave's current query row (pre-scaled)
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* Q = (const T*)p.Q + (size_t)b * p.Lq * p.ldq + h * p.dq;
+    const T* K = (const T*)p.K + (size_t)b * p.Lk * p.ldk + h * p.dq;
+    const T* V = (const T*)p.V + (size_t)b * p.Lk * p.ldv + h * p.dv;
+    T* O = (T*)p.O + (size_t)b * p.Lq * p.ldo + h * p.dv;
+    const int cq = p.dq >> 3, cv = p.dv >> 3;            // 16-B chunks per row
+    for (int i = tid; i < p.Lk * cq; i += 256) {
+        const int k = i / cq, c = i - k * cq;
+        const v8 t = *(const v8*)(K + (size_t)k * p.ldk + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kt[(size_t)(c * 8 + e) * LkP + k] = t[e];
+    }
+    for (int i = tid; i < (LkP - p.Lk) * p.dq; i += 256) {        // padding keys: finite zeros (masked below)
+        const int d = i / (LkP - p.Lk), k = p.Lk + i % (LkP - p.Lk);
+        kt[(size_t)d * LkP + k] = (T)0.f;
+    }
+    for (int i = tid; i < p.Lk * cv; i += 256) {
+        const int k = i / cv, c = i - k * cv;
+        *(v8*)(vs + (size_t)k * p.dv + c * 8) = *(const v8*)(V + (size_t)k * p.ldv + c * 8);
+    }
+    __syncthreads();
+    float* mypr = pr + wave * LkP;
+    float* myq = qr + wave * p.dq;
+    for (int q = wave; q < p.Lq; q += 4) {
+        for (int d = lane; d < p.dq; d += 64) myq[d] = to_f32(Q[(size_t)q * p.ldq + d]) * p.scale;
+        __builtin_amdgcn_wave_barrier();
+        float mx = -1e30f;
+        for (int k0 = 0; k0 < LkP; k0 += 64) {
+            const int k = k0 + lane;
+            float sc = 0.f;
+            for (int d = 0; d < p.dq; ++d) sc += myq[d] * to_f32(kt[(size_t)d * LkP + k]);
+            if (k >= p.Lk) sc = -1e30f;
+            mypr[k] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int k0 = 0; k0 < LkP; k0 += 64) {
+            const int k = k0 + lane;
+            const float e = k < p.Lk ? __expf(mypr[k] - mx) : 0.f;
+            mypr[k] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / sum;
+        for (int d = lane; d < p.dv; d += 64) {
+            float o = 0.f;
+            for (int k = 0; k < p.Lk; ++k) o += mypr[k] * to_f32(vs[(size_t)k * p.dv + d]);
+            O[(size_t)q * p.ldo + d] = from_f32<T>(o * inv);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int attention_small_launch(const SmallAttnParams& p, int dtype, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0 || p.dq <= 0 || p.dv <= 0 || p.Lk > 8192 || p.dq > 1024) {
         set_error("attention_small: unsupported shape"); return IMH_ERR_SHAPE;
+    }
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("attention_small: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    {   // LDS-resident form when the head's K^T and V fit and the rows are 16-B addressable
+        const int LkP = (p.Lk + 63) & ~63;
+        const size_t need = ((size_t)p.dq * LkP + (size_t)p.Lk * p.dv) * 2 + (size_t)(4 * LkP + 4 * p.dq) * sizeof(float);
+        const bool aligned = !(p.dq & 7) && !(p.dv & 7) && !(p.ldk & 7) && !(p.ldv & 7) && !(((size_t)p.Lk * p.dv * 2 + (size_t)p.dq * LkP * 2) & 15);
+        if (aligned && need <= 150 * 1024) {
+            dim3 grid(p.B * p.H);
+            if (dtype == IMH_DT_BF16) {
+                static bool a0 = false;
+                if (!a0) { hipFuncSetAttribute((const void*)attn_small_lds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a0 = true; }
+                hipLaunchKernelGGL((attn_small_lds_kernel<bf16_t>), grid, dim3(256), need, stream, p, LkP);
+            } else {
+                static bool a1 = false;
+                if (!a1) { hipFuncSetAttribute((const void*)attn_small_lds_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a1 = true; }
+                hipLaunchKernelGGL((attn_small_lds_kernel<f16_t>), grid, dim3(256), need, stream, p, LkP);
+            }
+            return check_launch("attn_small_lds_kernel");
+        }
     }
     const size_t lds = (size_t)(p.Lk + p.dq + 8) * sizeof(float);
     dim3 grid(p.B * p.H);

@@ -173,13 +173,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+                // the two waves that hold the same token rows (LN == 1: wn = 0 / 1; LN == 2: wm = 0 / 1) split the statistics
+                // work by k-slice: each takes the fragments of ONE of the two 32-wide halves of every K tile (wave-uniform
+                // branch) and the partial sums are exchanged through LDS after the loop
                 if constexpr (LN == 1) {
+                    if (kk == wn) {
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
+                        for (int i = 0; i < FM; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
+                    }
                 }
                 if constexpr (LN == 2) {
+                    if (kk == wm) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) frag_stats(wf[j], st_s[j], st_q[j]);
+                        for (int j = 0; j < FN; ++j) frag_stats(wf[j], st_s[j], st_q[j]);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -199,6 +206,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
         // every lane of a 16-lane row holds the partial sums of fragment row (lane & 15) over ITS 8-element k-slices:
         // combine the four lane groups (permlane swaps, no LDS), then mean / rstd per fragment row
         const float invk = 1.0f / (float)p.K;
+        {   // partner wave's half of the k-slices (the tile stages are dead: the K loop ended with a workgroup barrier)
+            float* ex = (float*)smem;
+            const int partner = LN == 1 ? (wave ^ 1) : (wave ^ 2);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                ex[((wave * NS + i) * 2 + 0) * 64 + lane] = st_s[i];
+                ex[((wave * NS + i) * 2 + 1) * 64 + lane] = st_q[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                st_s[i] += ex[((partner * NS + i) * 2 + 0) * 64 + lane];
+                st_q[i] += ex[((partner * NS + i) * 2 + 1) * 64 + lane];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const float su = xor32_sum(xor16_sum(st_s[i]));

@@ -424,6 +424,12 @@ static int launch_ring(const GemmParams& p, hipStream_t stream) {
 // (128x128 rings with 3-4 stages at one workgroup per CU and 256x128 with 2 stages were measured and dropped.)
 template <typename T, bool CONV>
 static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
+    // small-tile rings (4 waves, several workgroups per CU): the N = 1280 projections are latency-bound in the two-stage
+    // kernel (one 16 KB tile in flight per workgroup); 4000 + BM = 4-stage / 3-stage ring, 5000 + BM = 3-stage 64x64
+    if (bm == 4064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 4, CONV>(p, stream);
+    if (bm == 5064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 3, CONV>(p, stream);
+    if (bm == 4064 && bn == 128) return launch_ring<T, 64, 128, 2, 2, 3, CONV>(p, stream);
+    if (bm == 4128 && bn == 64) return launch_ring<T, 128, 64, 2, 2, 3, CONV>(p, stream);
     if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
     if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);

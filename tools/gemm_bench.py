@@ -17,6 +17,7 @@ SHAPES = [
     ("ff.geglu", 2048, 10240, 1280, None), ("ff.geglu", 8192, 5120, 640, None),
     ("ff.out", 2048, 1280, 5120, None), ("ff.out", 8192, 640, 2560, None),
     ("to_qk", 2048, 2560, 1280, None), ("to_q", 2048, 1280, 1280, None), ("to_qk", 8192, 1280, 640, None),
+    ("to_out@64", 8192, 640, 640, None), ("shortcut", 2048, 1280, 2560, None), ("shortcut@64", 8192, 640, 1920, None),
     ("conv1@128", 32768, 320, 2880, (2, 128, 128, 320, 1, 0)), ("conv2@64", 8192, 640, 5760, (2, 64, 64, 640, 1, 0)),
     ("conv2@32", 2048, 1280, 11520, (2, 32, 32, 1280, 1, 0)), ("upsample", 8192, 1280, 11520, (2, 32, 32, 1280, 1, 1)),
     ("conv1@32cat", 2048, 1280, 23040, (2, 32, 32, 2560, 1, 0)),
