@@ -327,10 +327,14 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
 }
 
 int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream);
+int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t stream);      // gemm_pp.hip: variant codes 8256 x 256, 9128 x 320
 
 template <typename T>
 static int launch_typed(const GemmParams& p, int conv, int bm, int bn, hipStream_t stream) {
     int rc;
+    if (bm == 8256 || bm == 9128 || bm == 9256) {
+        rc = gemm_pp_launch(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? IMH_DT_BF16 : IMH_DT_F16, conv, bm, stream);
+    } else
     if (bm >= 256) {
         rc = gemm_ring_launch(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? IMH_DT_BF16 : IMH_DT_F16, conv, bm, bn, stream);
     } else
@@ -430,7 +434,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || bm >= 256 || conv)) {
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256) && (p.flags & GF_LN_ROW))) || conv)) {
         set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_ring_kernel(const GemmPa
     constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
     constexpr int WT_BYTES = BN * GEMM_ROW_BYTES;
     constexpr int STAGE = XT_BYTES + WT_BYTES;
-    static_assert(FN == 4 || FN == 2, "lane owns 16 or 8 output columns");
+    static_assert(FN == 4 || FN == 2 || FN == 10 || FN == 5, "lane owns 8, 16, 20 or 40 output columns");
     static_assert(BM % RPR == 0 && BN % RPR == 0, "staging rounds");
     static_assert((S - 2) * LP <= 63, "vmcnt range");
     typedef typename Vec<T>::v8 v8;
@@ -430,6 +430,13 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     if (bm == 5064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 3, CONV>(p, stream);
     if (bm == 4064 && bn == 128) return launch_ring<T, 64, 128, 2, 2, 3, CONV>(p, stream);
     if (bm == 4128 && bn == 64) return launch_ring<T, 128, 64, 2, 2, 3, CONV>(p, stream);
+    // exact 256-way tilings of the M = 2048 / 8192 Linear layers (every CU gets the same number of equal tiles):
+    // 128 x 320 (8 waves, N = 10240 -> 512 tiles) and 64 x 160 (4 waves, N = 1280 -> 256 tiles, deep ring)
+    if (bm == 5256 && bn == 320) return launch_ring<T, 256, 320, 2, 2, 2, CONV>(p, stream);   // 4 waves, 320 accumulator registers
+    if (bm == 5258 && bn == 320) return launch_ring<T, 256, 320, 2, 4, 2, CONV>(p, stream);   // 8 waves, 160
+    if (bm == 6128 && bn == 320) return launch_ring<T, 128, 320, 4, 2, 2, CONV>(p, stream);
+    if (bm == 6064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 4, CONV>(p, stream);
+    if (bm == 7064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 3, CONV>(p, stream);
     if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
     if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);

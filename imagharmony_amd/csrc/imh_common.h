@@ -23,6 +23,9 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
+template <typename T> struct Pk2;
+template <> struct Pk2<__bf16> { typedef __attribute__((ext_vector_type(2))) __bf16 t; };
+template <> struct Pk2<_Float16> { typedef __attribute__((ext_vector_type(2))) _Float16 t; };
 template <typename T> struct Vec;
 template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
 template <> struct Vec<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };

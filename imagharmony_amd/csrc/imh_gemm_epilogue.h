@@ -58,37 +58,48 @@ enum : int {
     GF_LN_COL = 64,    // folded LayerNorm, stats per column n, ln_s / ln_c per row m
 };
 
-// vector load of CNT (4 | 8 | 16) consecutive T values into floats (16-B / 8-B accesses)
+// vector load / store of CNT (any even count) consecutive T values as floats: 16-B pieces, then one 8-B, then one 4-B piece
 template <typename T, int CNT>
 __device__ __forceinline__ void ldv(const T* p, float* o) {
-    if constexpr (CNT == 4) {
-        typename Vec<T>::v4 t = *(const typename Vec<T>::v4*)p;
+    static_assert(CNT % 2 == 0, "vector epilogue works on even column counts");
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = to_f32(t[e]);
-    } else {
+    for (int q0 = 0; q0 + 8 <= CNT; q0 += 8) {
+        typename Vec<T>::v8 t = *(const typename Vec<T>::v8*)(p + q0);
 #pragma unroll
-        for (int q0 = 0; q0 < CNT; q0 += 8) {
-            typename Vec<T>::v8 t = *(const typename Vec<T>::v8*)(p + q0);
+        for (int e = 0; e < 8; ++e) o[q0 + e] = to_f32(t[e]);
+    }
+    constexpr int R4 = CNT / 8 * 8;
+    if constexpr (CNT % 8 >= 4) {
+        typename Vec<T>::v4 t = *(const typename Vec<T>::v4*)(p + R4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[q0 + e] = to_f32(t[e]);
-        }
+        for (int e = 0; e < 4; ++e) o[R4 + e] = to_f32(t[e]);
+    }
+    if constexpr (CNT % 4 == 2) {
+        typename Pk2<T>::t t = *(const typename Pk2<T>::t*)(p + CNT - 2);
+        o[CNT - 2] = to_f32(t[0]); o[CNT - 1] = to_f32(t[1]);
     }
 }
 template <typename T, int CNT>
 __device__ __forceinline__ void stv(T* p, const float* v) {
-    if constexpr (CNT == 4) {
+    static_assert(CNT % 2 == 0, "vector epilogue works on even column counts");
+#pragma unroll
+    for (int q0 = 0; q0 + 8 <= CNT; q0 += 8) {
+        typename Vec<T>::v8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = from_f32<T>(v[q0 + e]);
+        *(typename Vec<T>::v8*)(p + q0) = t;
+    }
+    constexpr int R4 = CNT / 8 * 8;
+    if constexpr (CNT % 8 >= 4) {
         typename Vec<T>::v4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = from_f32<T>(v[e]);
-        *(typename Vec<T>::v4*)p = t;
-    } else {
-#pragma unroll
-        for (int q0 = 0; q0 < CNT; q0 += 8) {
-            typename Vec<T>::v8 t;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = from_f32<T>(v[q0 + e]);
-            *(typename Vec<T>::v8*)(p + q0) = t;
-        }
+        for (int e = 0; e < 4; ++e) t[e] = from_f32<T>(v[R4 + e]);
+        *(typename Vec<T>::v4*)(p + R4) = t;
+    }
+    if constexpr (CNT % 4 == 2) {
+        typename Pk2<T>::t t;
+        t[0] = from_f32<T>(v[CNT - 2]); t[1] = from_f32<T>(v[CNT - 1]);
+        *(typename Pk2<T>::t*)(p + CNT - 2) = t;
     }
 }
 

@@ -118,7 +118,10 @@ def sweep_shapes(rec, dtype):
                     if sp > 1 and (nkt // sp < 4 or -(-M // bm) * -(-N // bn) * sp > 2048):
                         continue
                     cands.append((bm, bn, sp))
-        cands += [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3128, 128, 2), (3064, 64, 1)]
+        cands += [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3128, 128, 2), (3064, 64, 1),
+                  (4128, 64, 1), (5064, 64, 1), (4064, 128, 1), (6128, 320, 1), (5258, 320, 1)]
+        if not conv:
+            cands += [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
         from tools.gemm_bench import graph_time
         for cfg in cands:
             try:
