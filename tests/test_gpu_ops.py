@@ -53,6 +53,50 @@ def test_gemm_plain(L, dtype, cfg, shape):
     assert_close(y, x.float() @ w.float().t(), dtype, f"gemm {shape} {cfg}")
 
 
+# variant codes of the big-tile / ring / ping-pong kernels (gemm_ring.hip, gemm_pp.hip): (bm code, bn, splits)
+BIG_VARIANTS = [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3064, 64, 1), (4128, 64, 1), (5064, 64, 1), (4064, 64, 1),
+                (4064, 128, 1), (6128, 320, 1), (5258, 320, 1), (6064, 160, 1), (8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", BIG_VARIANTS)
+def test_gemm_big_tile_variants(L, dtype, cfg):
+    """every ring / KG2 / ping-pong variant on tile-aligned, ragged and single-K-tile shapes, with bias + residual, bitwise
+    repeatable (the counted-vmcnt pipelines are race-screened by repetition)"""
+    ctx = ctx_for(dtype)
+    for (M, N, K) in [(512, 640, 64), (300, 520, 192), (640, 1280, 320), (2, 320, 128)]:
+        x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+        b, r = rnd(N, dtype=dtype, seed=3), rnd(M, N, dtype=dtype, seed=4)
+        ref = x.float() @ w.float().t() + b.float() + r.float()
+        y0 = ctx.gemm(x, w, bias=b, residual=r, cfg=cfg).clone()
+        assert_close(y0, ref, dtype, f"gemm {cfg} {(M, N, K)}")
+        for _ in range(3):
+            assert torch.equal(ctx.gemm(x, w, bias=b, residual=r, cfg=cfg), y0), f"{cfg} {(M, N, K)} not repeatable"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)])
+def test_gemm_pingpong_folded_layernorm_geglu(L, dtype, cfg):
+    """the ping-pong kernels with the folded LayerNorm (statistics split between the waves sharing the token rows) and
+    the GEGLU epilogue -- the ff.net.0 launch -- against F.layer_norm + matmul + gelu in fp32"""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    for (M, N, K) in [(512, 640, 128), (300, 960, 320), (2048, 2560, 640)]:
+        x = (rnd(M, K, dtype=dtype, seed=1) * 1.5 + 2.0).contiguous()
+        w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+        norm = torch.nn.LayerNorm(K, eps=1e-5)
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3)))
+            norm.bias.copy_(0.3 * torch.randn(K, generator=torch.Generator().manual_seed(4)))
+        full = (F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()).to(DEV)
+        wg, s, c = fold_ln(w, norm, ctx)
+        y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=cfg)
+        assert_close(y, full, dtype, f"folded LN {cfg} {(M, N, K)}", k=6.0)
+        g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg)
+        assert_close(g, full[:, 0::2] * F.gelu(full[:, 1::2]), dtype, f"folded LN + GEGLU {cfg} {(M, N, K)}", k=8.0)
+        assert torch.equal(g, ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(L, dtype):
     ctx = ctx_for(dtype)
@@ -120,7 +164,9 @@ def test_gemm_vt_perm(L, dtype, cfg):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [dict(B=2, H=16, W=16, Cin=64, Cout=128), dict(B=1, H=12, W=20, Cin=128, Cout=64),
                                   dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2), dict(B=2, H=8, W=8, Cin=64, Cout=64, up=1),
-                                  dict(B=2, H=8, W=8, Cin=192, Cout=4), dict(B=1, H=32, W=32, Cin=320, Cout=320, cfg=(128, 128, 2))])
+                                  dict(B=2, H=8, W=8, Cin=192, Cout=4), dict(B=1, H=32, W=32, Cin=320, Cout=320, cfg=(128, 128, 2)),
+                                  dict(B=1, H=32, W=32, Cin=128, Cout=640, cfg=(5258, 320, 1)), dict(B=2, H=16, W=24, Cin=64, Cout=320, up=1, cfg=(6128, 320, 1)),
+                                  dict(B=1, H=24, W=24, Cin=64, Cout=128, stride=2, cfg=(4128, 64, 1))])
 def test_conv3x3(L, dtype, case):
     ctx = ctx_for(dtype)
     B, H, W, Cin, Cout = case["B"], case["H"], case["W"], case["Cin"], case["Cout"]
