@@ -496,10 +496,12 @@ static int launch_pq(const GemmParams& p, hipStream_t stream) {
 //     64 x 160 = 4 x 10 accumulator fragments; lane owns 40 consecutive output columns.
 //   * four phases per K tile, ordered (k-half 0: weight fragments 0-5 | 6-9), (k-half 1: 0-5 | 6-9): 24 / 16 / 24 / 16
 //     MFMAs; the four token fragments of a k-half are read in its first phase and reused in its second.
-//   * staging parts: X + WA (token rows + weight rows 0-23 of every 40-row group; 7 LDS-DMA per thread) of tile t+2 are
-//     issued in phase 3 of tile t into tile t's own buffer (those rows were last read in phase 2); WB (rows 24-39;
-//     2 per thread) of tile t+1 in phase 0 of tile t.  Waits: vmcnt(2) after phase 2 (X + WA of t+1 landed, WB of t+1 may
-//     fly), vmcnt(7) after phase 3 (WB of t+1 landed, X + WA of t+2 may fly) -- each two segments before the first read.
+//   * staging, 9 LDS-DMA instructions per thread per K tile, 2-3 per load segment: phase 3 of tile t issues the first
+//     half of X of tile t+2 INTO TILE t's OWN BUFFER (its token rows were last read in phase 2); phase 0 of tile t+1 the
+//     second half, phase 1 WA (weight rows 0-23 of every 40-row group, what phases 0 / 2 read), phase 2 WB (rows 24-39)
+//     of tile t+2's predecessor ... i.e. in tile t: phase 0 X[128:256)(t+1), phase 1 WA(t+1), phase 2 WB(t+1), phase 3
+//     X[0:128)(t+2).  Waits: vmcnt(2) after phase 2 (X + WA of t+1 landed, WB of t+1 may fly) and vmcnt(2) after phase 3
+//     (WB of t+1 landed, the first X half of t+2 may fly) -- each two segments before the first read.
 constexpr int PR_BM = 256, PR_BN = 320;
 constexpr int PR_BUF = (PR_BM + PR_BN) * GEMM_ROW_BYTES;      // 72 KB per buffer
 constexpr int PR_WOFF = PR_BM * GEMM_ROW_BYTES;
@@ -541,11 +543,24 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
     }
     const unsigned char* Xb = (const unsigned char*)p.X;
     const unsigned char* Wb = (const unsigned char*)p.W;
-    auto stage_xa = [&](int buf, int kt) {
+    // X + WA of a tile go out in three groups (2 + 2 + 3 LDS-DMA instructions per thread) so that no load segment carries
+    // more than three: an LDS-DMA instruction costs 60-185 cycles of issue time (MI355X_MICROARCH.md), and a load segment
+    // longer than the partner's 16-24 MFMAs stretches the whole phase
+    auto stage_x01 = [&](int buf, int kt) {
         unsigned char* b = smem + buf * PR_BUF;
         const unsigned ko = (unsigned)kt * (unsigned)(GEMM_BK * sizeof(T));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(Xb + (ox[q] + ko), b + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+        for (int q = 0; q < 2; ++q) glds16(Xb + (ox[q] + ko), b + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+    };
+    auto stage_x23 = [&](int buf, int kt) {
+        unsigned char* b = smem + buf * PR_BUF;
+        const unsigned ko = (unsigned)kt * (unsigned)(GEMM_BK * sizeof(T));
+#pragma unroll
+        for (int q = 2; q < 4; ++q) glds16(Xb + (ox[q] + ko), b + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+    };
+    auto stage_wa = [&](int buf, int kt) {
+        unsigned char* b = smem + buf * PR_BUF;
+        const unsigned ko = (unsigned)kt * (unsigned)(GEMM_BK * sizeof(T));
 #pragma unroll
         for (int q = 0; q < 3; ++q) glds16(Wb + (oa[q] + ko), b + PR_WOFF + pq_piece_row(1, q, wave) * GEMM_ROW_BYTES);
     };
@@ -572,19 +587,31 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
         for (int j = 0; j < 10; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};   // LN: this wave's k-half (kk == wn) of token fragments 0-3
 
-    stage_xa(0, 0);
-    stage_wb(0, 0);
+    // prologue: tile 0 completely; of tile 1 the first X group (what phase 3 of "tile -1" would have issued)
+    stage_x01(0, 0); stage_x23(0, 0); stage_wa(0, 0); stage_wb(0, 0);
     if (nt > 1) {
-        stage_xa(1, 1);
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        stage_x01(1, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (wn == 1) __builtin_amdgcn_s_barrier();
 
-#define PR_END_L() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PR_END_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// PR_TIMING (tools/pp_phase_probe.py only): cycle counter at every segment boundary; wave 0 of workgroup 0 and wave 4
+// write their per-segment totals [issue part, wait part] to p.pf_ptr instead of prefetching
+#ifndef PR_TIMING
+#define PR_TIMING 0
+#endif
+#if PR_TIMING
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tm0 = __builtin_readcyclecounter();
+    int tseg = 0;
+#define PR_TICK(i) do { asm volatile("s_nop 0" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[i] += tn_ - tm0; tm0 = tn_; } while (0)
+#else
+#define PR_TICK(i) do {} while (0)
+#endif
+#define PR_END_L() do { PR_TICK(tseg * 4 + 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); PR_TICK(tseg * 4 + 1); } while (0)
+#define PR_END_M() do { __builtin_amdgcn_sched_barrier(0); PR_TICK(tseg * 4 + 2); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); PR_TICK(tseg * 4 + 3); } while (0)
 #define PR_MFMA(J0, NJ) do { __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
             acc[i][J0 + j] = mfma16(wf[j], xf[i], acc[i][J0 + j]); \
@@ -594,17 +621,24 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
         const unsigned char* sb = smem + cur * PR_BUF;
         v8 xf[4], wf[6];
         // ---------------- phase 0: k-half 0, weight fragments 0-5 ----------------
+#if PR_TIMING
+        tseg = 0;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *(const v8*)(sb + xoff[0] + i * 16 * GEMM_ROW_BYTES);
 #pragma unroll
         for (int j = 0; j < 6; ++j) wf[j] = *(const v8*)(sb + woff[0] + j * 4 * GEMM_ROW_BYTES);
-        if (t + 1 < nt) stage_wb(cur ^ 1, t + 1);
+        if (t + 1 < nt) stage_x23(cur ^ 1, t + 1);
         PR_END_L();
         PR_MFMA(0, 6);
         PR_END_M();
         // ---------------- phase 1: k-half 0, weight fragments 6-9 ----------------
+#if PR_TIMING
+        tseg = 1;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const v8*)(sb + woff[0] + (6 + j) * 4 * GEMM_ROW_BYTES);
+        if (t + 1 < nt) stage_wa(cur ^ 1, t + 1);
         if constexpr (LN == 1) {
             if (wn == 0) {
 #pragma unroll
@@ -615,19 +649,26 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
         PR_MFMA(6, 4);
         PR_END_M();
         // ---------------- phase 2: k-half 1, weight fragments 0-5 ----------------
+#if PR_TIMING
+        tseg = 2;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *(const v8*)(sb + xoff[1] + i * 16 * GEMM_ROW_BYTES);
 #pragma unroll
         for (int j = 0; j < 6; ++j) wf[j] = *(const v8*)(sb + woff[1] + j * 4 * GEMM_ROW_BYTES);
+        if (t + 1 < nt) stage_wb(cur ^ 1, t + 1);
         PR_END_L();
         PR_MFMA(0, 6);
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // X + WA of tile t+1 (WB of t+1 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PR_END_M();
         // ---------------- phase 3: k-half 1, weight fragments 6-9 ----------------
+#if PR_TIMING
+        tseg = 3;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const v8*)(sb + woff[1] + (6 + j) * 4 * GEMM_ROW_BYTES);
-        if (t + 2 < nt) stage_xa(cur, t + 2);                   // into THIS tile's buffer: its X / WA rows are dead
+        if (t + 2 < nt) stage_x01(cur, t + 2);                  // into THIS tile's buffer: its X rows are dead since phase 2
         if constexpr (LN == 1) {
             if (wn == 1) {
 #pragma unroll
@@ -636,13 +677,20 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
         }
         PR_END_L();
         PR_MFMA(6, 4);
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // WB of tile t+1 (X + WA of t+2 may fly)
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // WB of tile t+1 (first X group of t+2 may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PR_END_M();
     }
 #undef PR_END_L
 #undef PR_END_M
 #undef PR_MFMA
+#if PR_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && p.pf_ptr) {
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (wave >> 2) * 17;
+        for (int i = 0; i < 16; ++i) dbg[i] = tacc[i];
+        dbg[16] = nt;
+    }
+#endif
     if (wn == 0) __builtin_amdgcn_s_barrier();                  // balance the skew barrier
 
     // ---- epilogue: lane owns columns nb .. nb+39 of row m, handled as five 8-column pieces ----
@@ -691,7 +739,7 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
     };
     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
     row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
-    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+    if (!PR_TIMING) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
 template <typename T, int LN>
