@@ -333,9 +333,11 @@ def main():
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
         try:
-            pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")
+            pj = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+            if not os.path.exists(pj):
+                pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")
             traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_hbm_traffic_final.json (rocprofv3 --pmc, same command with --denoise-steps 4)"
+            traffic_src = f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command with --denoise-steps 4)"
         except (OSError, KeyError, ValueError):
             pass
         images = a.steps * world
@@ -356,7 +358,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g_by / n_g,
-                         "kernel": "imh::gemm_kernel (Linear + implicit-GEMM conv3x3 family)",
+                         "kernel": "imh::gemm_* (Linear + implicit-GEMM conv3x3 family: gemm_kernel, gemm_dual, gemm_ring, gemm_kg2, gemm_pq)",
                          "launches_per_step": n_g, "avg_launch_us": g_ms / n_g * 1e3,
                          "algorithmic_tflop_per_step": g_fl / 1e12,
                          "whole_forward_tflops": tot_fl / (dt / a.steps / a.denoise_steps) / 1e12},

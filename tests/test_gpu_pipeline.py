@@ -406,3 +406,54 @@ def test_generate_pns_two_stage_with_clip_judge():
     # the returned latent is the 30-step denoise of the winning noise
     direct = ip.generate_pns([r1["best_seed"]], output_type="latent", **kw)["latents"]
     assert torch.equal(direct, r1["latents"])
+
+
+def test_string_prompts_through_gpu_clip_text_encoders():
+    """SURVEY.md 8f-4 on the device: two stock transformers CLIP text encoders (random weights, stub tokenizers -- no
+    vocabulary offline) on the GPU behind imagharmony_amd.text.SDXLPromptEncoder feed IPAdapterXL.generate with STRING
+    prompts (ip_adapter.py:285-319 -> encode_prompt); the result equals the same run with the encoder's embeddings
+    passed in explicitly, and changes with the prompt."""
+    import numpy as np
+    from PIL import Image
+    from transformers import (CLIPImageProcessor, CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection, CLIPVisionConfig,
+                              CLIPVisionModelWithProjection)
+    from imagharmony_amd.ip_adapter import IPAdapterXL
+    from imagharmony_amd.modules import HarmonyAttention
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    from imagharmony_amd.text import SDXLPromptEncoder
+    from tests.test_text_encoder import _Tok
+    dtype = torch.bfloat16
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    cd, pd = ocfg.cross_attention_dim, ocfg.pooled_dim
+
+    class Tok77(_Tok):
+        model_max_length = 77
+    torch.manual_seed(0)
+    h1 = cd // 4
+    c1 = CLIPTextConfig(vocab_size=100, hidden_size=h1, intermediate_size=2 * h1, num_hidden_layers=2, num_attention_heads=4,
+                        max_position_embeddings=77, projection_dim=h1)
+    c2 = CLIPTextConfig(vocab_size=100, hidden_size=cd - h1, intermediate_size=cd, num_hidden_layers=2, num_attention_heads=4,
+                        max_position_embeddings=77, projection_dim=pd)
+    e1, e2 = CLIPTextModel(c1).eval().to(DEV, dtype), CLIPTextModelWithProjection(c2).eval().to(DEV, dtype)
+    enc = SDXLPromptEncoder(Tok77(), Tok77(), e1, e2)
+    pipe = StableDiffusionXLCustomPipeline(hu, device=DEV, dtype=dtype, text_encoder=enc)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                                          num_attention_heads=4, image_size=32, patch_size=8,
+                                                          projection_dim=128)).eval().to(DEV, dtype)
+    proc = CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32})
+    img = Image.fromarray((np.random.RandomState(0).rand(48, 40, 3) * 255).astype("uint8"))
+    ha = det_fill(HarmonyAttention(image_hidden_size=128, text_context_dim=cd, inter_dim=512, cross_heads=8,
+                                   reshape_blocks=8, cross_value_dim=64), 3)
+    ip = IPAdapterXL(pipe, None, None, DEV, num_tokens=4, inference=True, number_class_crossattention=ha, dtype=dtype,
+                     image_encoder=clip, clip_image_processor=proc)
+    det_fill(ip.image_proj_model, 5)
+    kw = dict(pil_image=img, num_samples=1, seed=7, num_inference_steps=2, guidance_scale=5.0, height=256, width=256,
+              output_type="latent")
+    a = ip.generate(prompt="a photo of three cats", negative_prompt="blurry", extra_text="three cats", **kw)
+    b = ip.generate(prompt="a photo of two dogs", negative_prompt="blurry", extra_text="two dogs", **kw)
+    assert a.shape == (1, 4, 32, 32) and torch.isfinite(a).all() and not torch.equal(a, b)
+    pe, ne, pp, npp = enc("a photo of three cats", negative_prompt="blurry")
+    assert pe.shape == (1, 77, cd) and pp.shape == (1, pd) and pe.is_cuda
+    ex = enc("three cats", do_classifier_free_guidance=False)[0]
+    c = ip.generate(prompt_embeds=(pe, ne, pp, npp), extra_prompt_embeds=ex, **kw)
+    assert torch.equal(a, c)

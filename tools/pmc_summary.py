@@ -22,7 +22,7 @@ def main():
         wr = w.get(k, {"avg": 0.0})["avg"] * 1024
         out[k] = dict(launches=f[k]["n"], fetch_bytes_per_launch=fe, write_bytes_per_launch=wr,
                       hbm_bytes_per_launch=fe + wr, avg_us_profiled=f[k]["avg_ns"] / 1e3)
-    gemm = {k: v for k, v in out.items() if "gemm_kernel" in k or "gemm_kg2" in k or "gemm_ring" in k}
+    gemm = {k: v for k, v in out.items() if any(t in k for t in ("gemm_kernel", "gemm_kg2", "gemm_ring", "gemm_dual", "gemm_pp", "gemm_pq", "gemm_pr"))}
     n = sum(v["launches"] for v in gemm.values())
     fam = dict(launches=n,
                fetch_bytes_per_launch=sum(v["fetch_bytes_per_launch"] * v["launches"] for v in gemm.values()) / n,
@@ -33,7 +33,7 @@ def main():
     json.dump(res, open(sys.argv[3], "w"), indent=1)
     if len(sys.argv) > 4:
         with open(sys.argv[4], "w") as md:
-            md.write("# HBM traffic per launch (rocprofv3 PMC, bench.py --denoise-steps 2)\n\n" + res["note"] + "\n\n")
+            md.write("# HBM traffic per launch (rocprofv3 PMC, bench.py --denoise-steps 4)\n\n" + res["note"] + "\n\n")
             md.write(f"GEMM family: {fam['launches']} launches, fetch {fam['fetch_bytes_per_launch']/1e6:.2f} MB + write "
                      f"{fam['write_bytes_per_launch']/1e6:.2f} MB = {fam['hbm_bytes_per_launch']/1e6:.2f} MB per launch\n\n")
             md.write("| kernel | launches | fetch MB | write MB | avg us (profiled) |\n|---|---|---|---|---|\n")
