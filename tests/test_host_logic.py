@@ -218,3 +218,17 @@ def test_no_packed_fp32_odd_register_selects_in_the_built_library():
     bad, n_objs, n_pk = offenders(lib.LIB_PATH)
     assert n_objs >= 6 and n_pk > 1000, (n_objs, n_pk)        # the disassembly really saw the kernels
     assert not bad, bad[:5]
+
+
+def test_integration_md_gemm_stub_matches_lib_and_header():
+    """the ctypes stub INTEGRATION.md shows integrators is the struct the library really takes (field names and order
+    equal imagharmony_amd.lib.GemmArgs, which test_ctypes_structs_match_header_field_order ties to include/imh.h)"""
+    import re
+    from imagharmony_amd import lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index("class GemmArgs(C.Structure):"):md.index("lib.imh_gemm.argtypes")]
+    fields = re.findall(r'\("(\w+)",\s*C\.(\w+)\)', block)
+    import ctypes as C
+    want = list(lib.GemmArgs._fields_)
+    assert [f[0] for f in fields] == [w[0] for w in want]
+    assert [getattr(C, f[1]) for f in fields] == [w[1] for w in want]       # c_int32 is c_int on this ABI: compare the types
