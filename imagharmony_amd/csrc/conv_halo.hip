@@ -1,0 +1,210 @@
+// conv3x3 (stride 1, pad 1, optional fused nearest x2 upsampling) with an LDS-resident input HALO for gfx950 -- the
+// ResnetBlock2D convolutions of the SDXL UNet at the 128 x 128 latent (diffusers ResnetBlock2D.conv1 / conv2, Upsample2D.conv;
+// call site ip_adapter/custom_pipelines.py:338-345).
+//
+// The implicit-GEMM kernels (gemm.hip, gemm_ring.hip) fetch the token operand once PER TAP: nine [pixels x 64 channel]
+// tiles per 64-channel chunk, i.e. every input pixel crosses the L2 -> LDS path nine times and (profiles/r01_pmc_*,
+// r02_pmc_*) 6-8x its size crosses the fabric.  Here a workgroup owns an 8 x 16 patch of output pixels: per 64-channel
+// chunk it stages the (8+2) x (16+2) input halo ONCE (180 pixels x 128 B = 22.5 KB, zero page for padding) and issues
+// all nine taps from it -- the MFMA token fragment of tap (ky, kx) for patch row py is the 16 consecutive halo pixels
+// (py + ky, kx .. kx + 15), a shifted window of the same LDS rows.  Weights stream as before ([320 couts x 64] per
+// (chunk, tap), double-buffered LDS-DMA).
+//   * 512 threads = 8 waves as 4 (patch row pairs) x 2 (cout halves of 160); wave tile 32 pixels x 160 couts = 2 x 10
+//     accumulator fragments of v_mfma_f32_16x16x32; lane owns 40 consecutive output channels (NHWC row).
+//   * halo rows are swizzled with (row & 7) (conflict-free for ANY window start under the ds_read_b128 bank model;
+//     the (row >> 1) & 7 swizzle of the GEMM tiles is 2-way for odd starts), weights with swz_w as in gemm_ring.hip.
+//   * LDS: 2 x 23 KB halo + 2 x 40 KB weights = 126 KB (86 KB for the 160-cout form), one workgroup per CU; two-stage pipeline over the
+//     9 * Cin / 64 (chunk, tap) steps, the next chunk's halo issued at tap 0 (nine steps of slack).
+// Epilogue: the shared one (bias, time-embedding row-add, residual).  Roofline: MFMA-bound, 2 * M * Cout * 9 Cin FLOP.
+#include "imh_common.h"
+#include "imh_kernels.h"
+#include "imh_gemm_epilogue.h"
+
+namespace imh {
+
+constexpr int CH_PW = 16;                                 // output patch width (one MFMA token fragment)
+constexpr int CH_HW = CH_PW + 2;                          // halo row length (18)
+// FN = weight fragments per wave: 10 -> 320 couts per workgroup (one tile per CU at the 128^2 latent with 320 channels),
+// 5 -> 160 couts (twice the workgroups: 256 at the 64^2 latent with 640 channels)
+// FM = token fragments (patch rows) per wave: 2 -> 8 x 16 patch (128 pixels), 1 -> 4 x 16 patch (64 pixels: twice the
+// workgroups again, for the 32^2 latent)
+template <typename T, int FN, int FM>
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
+    constexpr int CH_PH = 4 * FM;                           // output patch height
+    constexpr int CH_HALO = (CH_PH + 2) * CH_HW;            // 180 / 108 halo pixels
+    constexpr int HPIECES = (CH_HALO + 7) / 8;              // 23 / 14 staging pieces of 8 halo pixels
+    constexpr int HQ = (HPIECES + 7) / 8;                   // ... per wave
+    constexpr int CH_HALO_BYTES = HPIECES * 8 * GEMM_ROW_BYTES;
+    constexpr int CH_BN = 32 * FN;
+    constexpr int CH_W_BYTES = CH_BN * GEMM_ROW_BYTES;
+    constexpr int WPIECES = CH_BN / 8;                      // 8-row staging pieces of the weight tile
+    constexpr int WQ = (WPIECES + 7) / 8;                   // ... per wave
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo0 = smem;
+    unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // tile coordinates: cout tile fastest, then patch column, row, batch
+    int t = blockIdx.x;
+    const int tn = t % tiles_n; t /= tiles_n;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int n0 = tn * CH_BN;
+    const int Hv = p.H << p.up, Wv = p.Wd << p.up;          // virtual (upsampled) input = output size (stride 1)
+
+    // ---- halo staging: 23 pieces of 8 halo pixels; this wave takes pieces wave, wave + 8, wave + 16 ----
+    const unsigned char* hsrc[HQ];
+    int hstep[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int piece = q * 8 + wave;
+        const int h = piece * 8 + (lane >> 3);              // halo pixel index (may run past the halo on the last piece)
+        const int hy = h / CH_HW, hx = h - hy * CH_HW;
+        const int iy = ty * CH_PH + hy - 1, ix = tx * CH_PW + hx - 1;
+        const bool ok = piece < HPIECES && h < CH_HALO && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        const int c = (lane & 7) ^ (h & 7);
+        const size_t pix = ((size_t)b * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
+        hsrc[q] = ok ? (const unsigned char*)p.X + pix * p.Cin * sizeof(T) + c * 16 : g_zero_page + c * 16;
+        hstep[q] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+    }
+    auto stage_halo = [&](int buf, int ct) {
+        unsigned char* d = halo0 + buf * CH_HALO_BYTES;
+#pragma unroll
+        for (int q = 0; q < HQ; ++q)
+            if (q * 8 + wave < HPIECES) glds16(hsrc[q] + (size_t)ct * hstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+    };
+    // ---- weight staging: 40 pieces of 8 rows; this wave takes pieces wave + 8 q ----
+    const unsigned char* wsrc[WQ];
+    int wstep[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int row = (q * 8 + wave) * 8 + (lane >> 3);
+        const int c = stage_chunk_w(row, lane, FN);
+        const bool ok = q * 8 + wave < WPIECES && n0 + row < p.N;
+        wsrc[q] = ok ? (const unsigned char*)p.W + (size_t)(n0 + row) * p.ldw * sizeof(T) + c * 16 : g_zero_page + c * 16;
+        wstep[q] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+    }
+    const int cpt = p.Cin / GEMM_BK;                        // 64-channel chunks
+    auto stage_w = [&](int buf, int ct, int tap) {
+        unsigned char* d = wbuf0 + buf * CH_W_BYTES;
+        const size_t kt = (size_t)tap * cpt + ct;           // packed weight K index = (ky*3 + kx) * Cin + c
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (q * 8 + wave < WPIECES) glds16(wsrc[q] + kt * wstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+    };
+
+    // ---- fragment read offsets ----
+    // token fragment i = patch row FM wm + i; tap (ky, kx): halo rows (FM wm + i + ky) * 18 + kx + (lane & 15)
+    const int hrow0 = (FM * wm) * CH_HW + (lane & 15);
+    int woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int wr = wn * (16 * FN) + w_frag_row(lane & 15, 0, FN);
+        woff[kk] = tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = 9 * cpt;
+    stage_halo(0, 0);
+    stage_w(0, 0, 0);
+    int step = 0;
+    for (int ct = 0; ct < cpt; ++ct) {
+        const unsigned char* hb = halo0 + (ct & 1) * CH_HALO_BYTES;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of step `step` (and of the halo) landed
+            __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
+            asm volatile("" ::: "memory");
+            if (step + 1 < nsteps) {
+                const int nt = tap == 8 ? 0 : tap + 1;
+                stage_w((step + 1) & 1, tap == 8 ? ct + 1 : ct, nt);
+            }
+            if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
+            const unsigned char* wb = wbuf0 + (step & 1) * CH_W_BYTES;
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                v8 xf[FM], wf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int r = hrow0 + (i + ky) * CH_HW + kx;
+                    xf[i] = *(const v8*)(hb + r * GEMM_ROW_BYTES + (((kk * 4 + (lane >> 4)) ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(wb + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---- epilogue: lane owns couts nb .. nb + 4 FN - 1 of output pixel (oy, ox), stored as 4-column pieces (compile-time
+    //      indices: a rolled loop would turn acc[][] into a scratch array) ----
+    const int nb = n0 + wn * (16 * FN) + (lane >> 4) * (4 * FN);
+    const int ox = tx * CH_PW + (lane & 15);
+    auto piece = [&](auto I, auto J, int m) {
+        constexpr int i = decltype(I)::value, j = decltype(J)::value;
+        if constexpr (j < FN && i < FM) {
+            float v[4];
+            const float none[8] = {};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            epilogue_store_pre<T, 1>(p, v, m, nb + 4 * j, none, false);
+        }
+    };
+    auto row = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i >= FM) return;
+        const int oy = ty * CH_PH + FM * wm + (i < FM ? i : 0);
+        if (oy >= p.Ho || ox >= p.Wo || nb >= p.N) return;
+        const int m = (b * p.Ho + oy) * p.Wo + ox;
+        piece(I, std::integral_constant<int, 0>{}, m); piece(I, std::integral_constant<int, 1>{}, m);
+        piece(I, std::integral_constant<int, 2>{}, m); piece(I, std::integral_constant<int, 3>{}, m);
+        piece(I, std::integral_constant<int, 4>{}, m); piece(I, std::integral_constant<int, 5>{}, m);
+        piece(I, std::integral_constant<int, 6>{}, m); piece(I, std::integral_constant<int, 7>{}, m);
+        piece(I, std::integral_constant<int, 8>{}, m); piece(I, std::integral_constant<int, 9>{}, m);
+    };
+    row(std::integral_constant<int, 0>{});
+    row(std::integral_constant<int, 1>{});
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+}
+
+// variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts
+int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
+    const int ph = bm == 7564 ? 4 : 8;
+    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160)) {
+        set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 only (stride=%d splits=%d Cin=%d bn=%d)", p.stride, p.splits, p.Cin, bn);
+        return IMH_ERR_ARG;
+    }
+    if (p.Ho != (p.H << p.up) || p.Wo != (p.Wd << p.up)) { set_error("conv_halo: output size must equal the (upsampled) input size"); return IMH_ERR_SHAPE; }
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("conv_halo: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    const int B = p.M / (p.Ho * p.Wo);
+    const int tiles_x = (p.Wo + CH_PW - 1) / CH_PW, tiles_y = (p.Ho + ph - 1) / ph, tiles_n = (p.N + bn - 1) / bn;
+    dim3 grid(B * tiles_y * tiles_x * tiles_n);
+    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + 2 * bn * GEMM_ROW_BYTES;
+#define IMH_CH2(TT, FNV, FMV) do { auto kern = conv_halo_kernel<TT, FNV, FMV>; static bool attr_set = false; \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
+#define IMH_CH(TT, FNV) do { if (ph == 8) IMH_CH2(TT, FNV, 2); else IMH_CH2(TT, FNV, 1); } while (0)
+    if (dtype == IMH_DT_BF16) { if (bn == 320) IMH_CH(bf16_t, 10); else IMH_CH(bf16_t, 5); }
+    else { if (bn == 320) IMH_CH(f16_t, 10); else IMH_CH(f16_t, 5); }
+#undef IMH_CH
+#undef IMH_CH2
+    return check_launch("conv_halo_kernel");
+}
+
+}  // namespace imh

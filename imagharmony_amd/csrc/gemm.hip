@@ -327,11 +327,16 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
 }
 
 int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream);
+int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream);       // conv_halo.hip: variant codes 7128 / 7564 x 320 / 160
 int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t stream);      // gemm_pp.hip: variant codes 8256 x 256, 9128 x 320
 
 template <typename T>
 static int launch_typed(const GemmParams& p, int conv, int bm, int bn, hipStream_t stream) {
     int rc;
+    if (bm == 7128 || bm == 7564) {
+        if (!conv) { set_error("gemm: variant 7128 is the halo conv3x3 kernel"); return IMH_ERR_ARG; }
+        rc = conv_halo_launch(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? IMH_DT_BF16 : IMH_DT_F16, bm, bn, stream);
+    } else
     if (bm == 8256 || bm == 9128 || bm == 9256) {
         rc = gemm_pp_launch(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? IMH_DT_BF16 : IMH_DT_F16, conv, bm, stream);
     } else

@@ -146,15 +146,15 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
             const float mean = ln->mean, rstd = ln->rstd;
             if (have_pre) {              // s_n, c_n preloaded once per lane by the caller (ln_preload)
 #pragma unroll
-                for (int q = 0; q < NV; ++q) v[q] = rstd * (v[q] - mean * lnpre[q]) + lnpre[NV + q];
+                for (int q = 0; q < NV; ++q) v[q] = fma_nopk(rstd, fma_nopk(-mean, lnpre[q], v[q]), lnpre[NV + q]);
             } else {
 #pragma unroll
-                for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] = rstd * (v[q] - mean * p.ln_s[nb + q]) + p.ln_c[nb + q];
+                for (int q = 0; q < NV; ++q) if (nb + q < N) v[q] = fma_nopk(rstd, fma_nopk(-mean, p.ln_s[nb + q], v[q]), p.ln_c[nb + q]);
             }
         } else {                         // y = rstd_n * (acc - mean_n * s_m) + c_m
             const float sm = p.ln_s[m], cm = p.ln_c[m];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) v[q] = ln->cr[q] * (v[q] - ln->cm[q] * sm) + cm;
+            for (int q = 0; q < NV; ++q) v[q] = fma_nopk(ln->cr[q], fma_nopk(-ln->cm[q], sm, v[q]), cm);
         }
     }
     if ((p.flags & GF_VT_PERM) && FN == 4) {   // V^T key permutation: swap the 2nd and 3rd run of 4

@@ -166,7 +166,13 @@ def test_gemm_vt_perm(L, dtype, cfg):
                                   dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2), dict(B=2, H=8, W=8, Cin=64, Cout=64, up=1),
                                   dict(B=2, H=8, W=8, Cin=192, Cout=4), dict(B=1, H=32, W=32, Cin=320, Cout=320, cfg=(128, 128, 2)),
                                   dict(B=1, H=32, W=32, Cin=128, Cout=640, cfg=(5258, 320, 1)), dict(B=2, H=16, W=24, Cin=64, Cout=320, up=1, cfg=(6128, 320, 1)),
-                                  dict(B=1, H=24, W=24, Cin=64, Cout=128, stride=2, cfg=(4128, 64, 1))])
+                                  dict(B=1, H=24, W=24, Cin=64, Cout=128, stride=2, cfg=(4128, 64, 1)),
+                                  # halo kernel: aligned, ragged patch grid, several cout tiles, fused x2 upsampling, tiny
+                                  dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 320, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=64, cfg=(7128, 320, 1)),
+                                  dict(B=1, H=24, W=16, Cin=192, Cout=704, cfg=(7128, 320, 1)), dict(B=2, H=8, W=8, Cin=64, Cout=320, up=1, cfg=(7128, 320, 1)),
+                                  dict(B=1, H=3, W=5, Cin=64, Cout=8, cfg=(7128, 320, 1)),
+                                  dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(7128, 160, 1)),
+                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=10, W=20, Cin=64, Cout=384, cfg=(7564, 320, 1))])
 def test_conv3x3(L, dtype, case):
     ctx = ctx_for(dtype)
     B, H, W, Cin, Cout = case["B"], case["H"], case["W"], case["Cin"], case["Cout"]

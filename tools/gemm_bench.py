@@ -21,6 +21,7 @@ SHAPES = [
     ("conv1@128", 32768, 320, 2880, (2, 128, 128, 320, 1, 0)), ("conv2@64", 8192, 640, 5760, (2, 64, 64, 640, 1, 0)),
     ("conv2@32", 2048, 1280, 11520, (2, 32, 32, 1280, 1, 0)), ("upsample", 8192, 1280, 11520, (2, 32, 32, 1280, 1, 1)),
     ("conv1@32cat", 2048, 1280, 23040, (2, 32, 32, 2560, 1, 0)),
+    ("conv1@128cat", 32768, 320, 8640, (2, 128, 128, 960, 1, 0)), ("up@64->128", 32768, 640, 5760, (2, 64, 64, 640, 1, 1)),
 ]
 
 

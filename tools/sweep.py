@@ -122,6 +122,8 @@ def sweep_shapes(rec, dtype):
                   (4128, 64, 1), (5064, 64, 1), (4064, 128, 1), (6128, 320, 1), (5258, 320, 1)]
         if not conv:
             cands += [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
+        elif geom[4] == 1:
+            cands += [(7128, 320, 1), (7128, 160, 1), (7564, 320, 1), (7564, 160, 1)]           # LDS-halo conv kernel (stride 1 only)
         from tools.gemm_bench import graph_time
         for cfg in cands:
             try:
