@@ -14,7 +14,7 @@ import torch
 from . import lib as L
 
 _DT = {torch.bfloat16: L.IMH_DT_BF16, torch.float16: L.IMH_DT_F16}
-_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning.json")
+_TUNING_PATH = os.environ.get("IMH_TUNING_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning.json")   # override: A/B runs
 
 
 _TUNING_CACHE = None
