@@ -60,7 +60,15 @@ def denoise_pair(device, dtype, steps=2, hw=32, guidance=5.0, scheduler="ddim", 
 
 
 def run_smoke(device):
+    """fp16 is the sharp check (its rounding noise is 8x finer than bf16's: any indexing / layout / schedule error shows up
+    far above the bound); the bf16 run -- the benchmark dtype -- is held to the bf16 noise floor of this 2-step, CFG-5
+    trajectory (weights AND activations rounded to 8 bits, the cond / uncond difference amplified 5x), the same bound
+    as tests/test_gpu_pipeline.py's 3-step trajectories"""
+    out16, ref = denoise_pair(device, torch.float16, steps=2)
+    r16 = rel_rms(out16, ref)
     out, ref = denoise_pair(device, torch.bfloat16, steps=2)
     r = rel_rms(out, ref)
-    print(f"smoke: 2-step DDIM denoise (tiny UNet, CFG 5.0, IP tokens 4) rel-rms vs CPU oracle = {r:.3e}")
-    assert torch.isfinite(out).all() and r < 3e-2, r
+    print(f"smoke: 2-step DDIM denoise (tiny UNet, CFG 5.0, IP tokens 4) rel-rms vs CPU oracle: fp16 {r16:.3e} (< 6e-3), "
+          f"bf16 {r:.3e} (< 4e-2)")
+    assert torch.isfinite(out16).all() and r16 < 6e-3, r16
+    assert torch.isfinite(out).all() and r < 4e-2, r
