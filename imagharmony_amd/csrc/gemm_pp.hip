@@ -448,6 +448,16 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
             rstd[i] = rsqrtf(fmaxf(sq * invk - mean[i] * mean[i], 0.f) + p.ln_eps);
         }
     }
+    // s_n, c_n of all five pieces and the bias are fetched once, ahead of the first store (see EpiPre)
+    float lnpre[5][16];
+    bool have_pre[5];
+    EpiPre<8> pre[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        have_pre[c] = ln_preload<8>(p, nb + 8 * c, lnpre[c]);
+        pre[c].ok = !p.rowadd && !p.residual && epilogue_fast<T, 8>(p, nb + 8 * c);
+        if (pre[c].ok && p.bias) ldv<T, 8>((const T*)p.bias + nb + 8 * c, pre[c].bias);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 32 + i * 16 + (lane & 15);
@@ -455,13 +465,12 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
         if constexpr (LN == 1) { ln.mean = mean[i]; ln.rstd = rstd[i]; }
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-            float v[8], lnpre[16];
+            float v[8];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][2 * c + jj][r];
-            const bool have_pre = ln_preload<8>(p, nb + 8 * c, lnpre);
-            epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre, have_pre, LN != 0 ? &ln : nullptr);
+            epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre[c], have_pre[c], LN != 0 ? &ln : nullptr, &pre[c]);
         }
     }
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);

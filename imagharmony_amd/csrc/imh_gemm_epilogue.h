@@ -126,12 +126,39 @@ __device__ __forceinline__ bool ln_preload(const GemmParams& p, int nb, float (&
     return true;
 }
 
+// Operands of the epilogue fetched AHEAD of the stores (epilogue_preload): a kernel that finishes a lane's columns in
+// several pieces would otherwise run  load - wait - compute - store  once per piece -- the compiler may not hoist a load of
+// bias / row-add / residual above the previous piece's store to Y (they could alias as far as C++ knows), and with one
+// workgroup per CU nothing hides those round trips (measured: +12-15 us on the 256 x 320 / 128 x 320 GEGLU launches).
+// Hoisting by hand is safe even for an in-place residual (Y == residual): every element is read before ITS OWN store,
+// by the same lane.  Only valid on the fast path (vector-aligned operands, whole piece in range).
+template <int NV>
+struct EpiPre {
+    float bias[NV], radd[NV], res[NV];      // res holds NV / 2 values for GEGLU
+    bool ok;                                 // operands are in here (fast path); false -> the epilogue loads them itself
+};
+template <typename T, int NV>
+__device__ __forceinline__ bool epilogue_fast(const GemmParams& p, int nb) {
+    return (nb + NV <= p.N) && !(p.ldy & 7) && (!p.residual || !(p.ldr & 7)) && (!p.rowadd || !(p.ldra & 7));
+}
+template <typename T, int NV>
+__device__ __forceinline__ void epilogue_preload(const GemmParams& p, int m, int nb, EpiPre<NV>& e, bool row_ok) {
+    e.ok = row_ok && epilogue_fast<T, NV>(p, nb);
+    if (!e.ok) return;
+    if (p.bias) ldv<T, NV>((const T*)p.bias + nb, e.bias);
+    if (p.rowadd) ldv<T, NV>((const T*)p.rowadd + (size_t)(m / p.rows_per_batch) * p.ldra + nb, e.radd);
+    if (p.residual) {
+        if (p.flags & GF_GEGLU) ldv<T, NV / 2>((const T*)p.residual + (size_t)m * p.ldr + (nb >> 1), e.res);
+        else ldv<T, NV>((const T*)p.residual + (size_t)m * p.ldr + nb, e.res);
+    }
+}
+
 // Epilogue of one lane: NV = 4*FN consecutive columns nb.. of row m.
 // Fast path (whole vector in range, 16-B aligned operands): vector loads/stores only.
 template <typename T, int FN>
 __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&v)[4 * FN], int m, int nb,
                                                    const float (&lnpre)[8 * FN], const bool have_pre,
-                                                   const LnArgs<4 * FN>* ln = nullptr) {
+                                                   const LnArgs<4 * FN>* ln = nullptr, const EpiPre<4 * FN>* pre = nullptr) {
     constexpr int NV = 4 * FN;
     constexpr int NH = NV / 2;
     const T* bias = (const T*)p.bias;
@@ -139,7 +166,8 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
     const T* res = (const T*)p.residual;
     const int N = p.N;
     const bool geglu = p.flags & GF_GEGLU;
-    const bool fast = (nb + NV <= N) && !(p.ldy & 7) && (!res || !(p.ldr & 7)) && (!rowadd || !(p.ldra & 7));
+    const bool fast = epilogue_fast<T, NV>(p, nb);
+    const bool use_pre = pre && pre->ok;     // implies fast
     float t[NV];
     if (ln && (p.flags & (GF_LN_ROW | GF_LN_COL))) {
         if (p.flags & GF_LN_ROW) {       // y = rstd_m * (acc - mean_m * s_n) + c_n
@@ -161,7 +189,14 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
 #pragma unroll
         for (int r = 0; r < 4; ++r) { float t = v[4 + r]; v[4 + r] = v[8 + r]; v[8 + r] = t; }
     }
-    if (fast) {
+    if (use_pre) {
+        if (bias) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += pre->bias[q]; }
+        if (rowadd) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += pre->radd[q]; }
+    } else if (fast) {
         if (bias) { ldv<T, NV>(bias + nb, t);
 #pragma unroll
             for (int q = 0; q < NV; ++q) v[q] += t[q]; }
@@ -189,7 +224,10 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
         for (int q = 0; q < NH; ++q) v[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
         T* y = (T*)p.Y + (size_t)m * p.ldy + ob;
         if (fast) {
-            if (res) { ldv<T, NH>(res + (size_t)m * p.ldr + ob, t);
+            if (res && use_pre) {
+#pragma unroll
+                for (int q = 0; q < NH; ++q) v[q] += pre->res[q];
+            } else if (res) { ldv<T, NH>(res + (size_t)m * p.ldr + ob, t);
 #pragma unroll
                 for (int q = 0; q < NH; ++q) v[q] += t[q]; }
             stv<T, NH>(y, v);
@@ -202,7 +240,10 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
         }
         return;
     }
-    if (res) {
+    if (res && use_pre) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] += pre->res[q];
+    } else if (res) {
         const T* rr = res + (size_t)m * p.ldr + nb;
         if (fast) { ldv<T, NV>(rr, t);
 #pragma unroll
