@@ -388,6 +388,244 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
     if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, blockDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------
+// "WS": wave-specialised variant for the M = 2048, N = 1280 layers (to_out, ff.out, the 32 x 32 convolutions).
+// Those problems tile 256 ways only as 64 x 160, and at that size the vector-memory front end is the longest
+// pipe of the CU: every 16-B piece of both operands goes through the address unit at 64 B / clk / CU
+// (tools/micro/glds_rate.hip), 448 cycles per K tile against 320 cycles of MFMA time, and a wave that is queued
+// behind that unit with an LDS-DMA instruction cannot issue its MFMAs (tools/hot_probe.py: cache-hot operands
+// change nothing).  So the roles are split: NP producer waves do nothing but issue the LDS-DMA ring (own vmcnt
+// counters, S - 1 tiles ahead), four consumer waves (2 x 2 over the tile) only read fragments and issue MFMAs,
+// with the fragments of tile i + 1 read into a second register set while the MFMAs of tile i run, so that a
+// consumer never waits on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1
+// has landed" (producers wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt
+// before arriving), after which the producers refill tile i's slot.
+#ifndef WS_ABL
+#define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
+#endif
+template <typename T, int BM, int BN, int S, int NP, bool CONV>
+__global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmParams p) {
+    constexpr int TM = BM / 2, TN = BN / 2;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
+    constexpr int NI = (BM + BN) / 8;              // ... and in total
+    constexpr int LP = NI / NP, KX = NIX / NP;     // per producer wave
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;
+    static_assert(NI % NP == 0 && NIX % NP == 0, "instructions split evenly between the producers");
+    static_assert((S - 2) * LP <= 63, "vmcnt range");
+    static_assert(TN % (4 * FN) == 0, "weight fragment rows");
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
+    const int nkt = p.K / GEMM_BK;
+    const int z = blockIdx.y;
+    const int per = (nkt + p.splits - 1) / p.splits;
+    const int kt0 = z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    const int nt = max(0, kt1 - kt0);
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producer
+        const int pw = wave - 4;
+        const unsigned char* zero = g_zero_page;
+        const unsigned char* base[LP];
+        int step[LP];
+        int cb[KX > 0 ? KX : 1], coy[KX > 0 ? KX : 1], cox[KX > 0 ? KX : 1];
+        bool cvalid[KX > 0 ? KX : 1];
+#pragma unroll
+        for (int k = 0; k < LP; ++k) {
+            const int r = (k * NP + pw) * 8 + (lane >> 3);    // row of the stage: token rows, then weight rows
+            if (k < KX) {
+                const int c = stage_chunk_x(r, lane);
+                const int m = m0 + r;
+                const bool ok = m < p.M;
+                if (!CONV) {
+                    base[k] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+                    step[k] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+                } else {
+                    const int hw = p.Ho * p.Wo;
+                    const int b = m / hw;
+                    const int rem = m - b * hw;
+                    const int oy = rem / p.Wo;
+                    cb[k] = b; coy[k] = oy; cox[k] = rem - oy * p.Wo; cvalid[k] = ok;
+                    base[k] = zero + c * 16;
+                    step[k] = 0;
+                }
+            } else {
+                const int row = r - BM;
+                const int c = stage_chunk_w(row, lane, FN);
+                const int n = n0 + row;
+                const bool ok = n < p.N;
+                base[k] = ok ? (const unsigned char*)p.W + ((size_t)n * p.ldw) * sizeof(T) + c * 16 : zero + c * 16;
+                step[k] = ok ? GEMM_BK * (int)sizeof(T) : 0;
+            }
+        }
+        const int cpt = CONV ? p.Cin / GEMM_BK : 1;
+        auto issue = [&](int slot, int kt) {
+            unsigned char* st = smem + slot * STAGE;
+            int ky = 0, kx = 0, ct = 0;
+            if (CONV) {
+                const int tap = kt / cpt;
+                ct = kt - tap * cpt;
+                ky = tap / 3; kx = tap - ky * 3;
+            }
+#pragma unroll
+            for (int k = 0; k < LP; ++k) {
+                unsigned char* dst = st + (k * NP + pw) * 8 * GEMM_ROW_BYTES;
+                if (CONV && k < KX) {
+                    const int r = (k * NP + pw) * 8 + (lane >> 3);
+                    const int c = stage_chunk_x(r, lane);
+                    const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+                    const int iy = coy[k] * p.stride + ky - 1;
+                    const int ix = cox[k] * p.stride + kx - 1;
+                    const bool ok = cvalid[k] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                    const size_t pix = ((size_t)cb[k] * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
+                    const unsigned char* src = ok
+                        ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
+                        : zero + c * 16;
+                    if (!(WS_ABL & 2)) glds16(src, dst);
+                } else {
+                    if (!(WS_ABL & 2)) glds16(base[k] + (size_t)kt * step[k], dst);
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nt) issue(s, kt0 + s);
+        if (S - 1 <= nt) wait_vmcnt<(S - 2) * LP>();          // tile 0 has landed
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int slot = S - 1;                                     // slot of tile i + S - 1
+        for (int i = 0; i < nt; ++i) {
+            if (i + S - 1 < nt) issue(slot, kt0 + i + S - 1); // the slot tile i - 1 was read from
+            if (i + S <= nt) wait_vmcnt<(S - 2) * LP>();      // tile i + 1 has landed
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (++slot == S) slot = 0;
+        }
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 256, 64 * NP);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int wm = wave >> 1, wn = wave & 1;
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int xr = wm * TM + (lane & 15);
+        const int wr = wn * TN + w_frag_row(lane & 15, 0, FN);
+        xoff[kk] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
+        woff[kk] = XT_BYTES + tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8 xf[2][FM], wf[2][FN];                       // register set kk holds k step kk of the tile being consumed
+    auto rd = [&](auto KK, int slot) {
+        constexpr int kk = decltype(KK)::value;
+        const unsigned char* st = smem + slot * STAGE;
+        if (WS_ABL & 4) return;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xf[kk][i] = *(const v8*)(st + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[kk][j] = *(const v8*)(st + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+    };
+    auto mm = [&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        if (WS_ABL & 1) {                          // keep the fragment reads alive without the MFMAs
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(xf[kk][i]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[kk][j]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[kk][j], xf[kk][i], acc[i][j]);
+    };
+    const std::integral_constant<int, 0> K0{};
+    const std::integral_constant<int, 1> K1{};
+    // issue order of one half interval: the fragment reads of the next k step interleaved one-to-one with the first
+    // MFMAs of the previous one, the remaining MFMAs behind them (the reads return under the MFMA pipe time)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int k = 0; k < FM + FN; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
+    };
+    __builtin_amdgcn_s_barrier();                  // tile 0 has landed
+    asm volatile("" ::: "memory");
+    int slot = 0;
+    for (int i = 0; i < nt; ++i) {
+        rd(K0, slot);                              // (i, k step 0)  beside the MFMAs of (i - 1, k step 1)
+        if (i > 0) mm(K1);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        rd(K1, slot);                              // (i, k step 1)  beside the MFMAs of (i, k step 0)
+        mm(K0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile i has been read: its slot may be refilled
+        __builtin_amdgcn_s_barrier();                            // ... and tile i + 1 has landed
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (++slot == S) slot = 0;
+    }
+    if (nt > 0) mm(K1);
+
+    const int nb = n0 + wn * TN + (lane >> 4) * 4 * FN;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        if (m >= p.M || nb >= p.N) continue;
+        float v[4 * FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+        if (p.splits > 1) {
+            float* o = p.partial + ((size_t)z * p.M + m) * p.N + nb;
+            if (nb + 4 * FN <= p.N && (p.N & 3) == 0) {
+#pragma unroll
+                for (int q0 = 0; q0 < 4 * FN; q0 += 4) *(f32x4*)(o + q0) = f32x4{v[q0], v[q0 + 1], v[q0 + 2], v[q0 + 3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
+            }
+        } else {
+            epilogue_store<T, FN>(p, v, m, nb);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int S, int NP, bool CONV>
+static int launch_ws(const GemmParams& p, hipStream_t stream) {
+    GemmParams q = p;
+    int tiles;
+    xcd_partition(q, BM, BN, &tiles);
+    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
+    auto kern = gemm_ws_kernel<T, BM, BN, S, NP, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * (4 + NP)), smem, stream, q);
+    return check_launch("gemm_ws_kernel");
+}
+
 template <typename T, int BM, int BN, bool CONV>
 static int launch_kg2(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
@@ -439,6 +677,12 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     if (bm == 7064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 3, CONV>(p, stream);
     if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
     if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
+    // wave-specialised 64 x 160, 4-stage ring, four consumer waves + two (1464) / four (2464) producer waves
+    // (a fifth stage measured no different)
+    if (bm == 1464 && bn == 160) return launch_ws<T, 64, 160, 4, 2, CONV>(p, stream);
+    if (bm == 2464 && bn == 160) return launch_ws<T, 64, 160, 4, 4, CONV>(p, stream);   // four producer waves
+    if (bm == 24128 && bn == 160) return launch_ws<T, 128, 160, 4, 4, CONV>(p, stream);  // M = 8192, N = 640: 256 tiles
+    if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 4, 4, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);
     if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
     set_error("gemm_ring: unsupported variant %dx%d", bm, bn);

@@ -6,7 +6,10 @@ from imagharmony_amd.ctx import Ctx
 from tools.gemm_bench import graph_time
 DEV = "cuda:0"; dtype = torch.bfloat16
 for (name, M, N, K, cfg) in [("geglu", 2048, 10240, 1280, (128, 128, 1)), ("to_out", 2048, 1280, 1280, (64, 64, 1)),
-                             ("ff.out", 2048, 1280, 5120, (64, 64, 1)), ("qk", 2048, 2560, 1280, (128, 128, 1))]:
+                             ("ff.out", 2048, 1280, 5120, (64, 64, 1)), ("qk", 2048, 2560, 1280, (128, 128, 1)),
+                             ("to_out", 2048, 1280, 1280, (6064, 160, 1)), ("to_out", 2048, 1280, 1280, (5064, 64, 1)),
+                             ("ff.out", 2048, 1280, 5120, (4128, 64, 1)), ("ff.out", 2048, 1280, 5120, (6064, 160, 1)),
+                             ("geglu", 2048, 10240, 1280, (9128, 320, 1)), ("geglu", 2048, 10240, 1280, (9256, 320, 1))]:
     x = torch.randn(M, K, device=DEV).to(dtype); w = (torch.randn(N, K, device=DEV) * K ** -0.5).to(dtype)
     out = torch.empty(M, N, device=DEV, dtype=dtype)
     r = {}

@@ -85,7 +85,7 @@ def summarize(rec, ms, wall_ms, label):
     return dict(label=label, n_ops=len(ms), sum_ms=tot, wall_ms=wall_ms, by_descr=by)
 
 
-def sweep_shapes(rec, dtype):
+def sweep_shapes(rec, dtype, extra=None, base=None):
     l = rec.lib
     shapes = collections.OrderedDict()
     for (tag, kind, descr, fl, by_, shape, *rest) in rec.tags:
@@ -124,6 +124,10 @@ def sweep_shapes(rec, dtype):
             cands += [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
         elif geom[4] == 1:
             cands += [(7128, 320, 1), (7128, 160, 1), (7564, 320, 1), (7564, 160, 1)]           # LDS-halo conv kernel (stride 1 only)
+        if extra:                      # incremental: the current table entry against the new variants only
+            key = f"{M},{N},{K},{conv}"
+            cands = [tuple(base[key])] if base and key in base else [tuple(ctx._config(M, N, K, conv, 0))]
+            cands += [c for c in extra if c not in cands]
         from tools.gemm_bench import graph_time
         for cfg in cands:
             try:
@@ -150,6 +154,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--candidates", type=int, default=1, help="PNS candidates stacked per forward (UNet batch 2S)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
+    ap.add_argument("--extra", default="", help="incremental sweep: 'bm,bn,splits;...' tried against the current tuning.json entry only")
     a = ap.parse_args()
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
     os.makedirs(a.out, exist_ok=True)
@@ -160,7 +165,9 @@ def main():
     results = [summarize(rec, ms, wall, "heuristic configs")]
     assert torch.isfinite(out.float()).all(), "non-finite UNet output"
     if not a.no_sweep:
-        table, report = sweep_shapes(rec, dtype)
+        extra = [tuple(int(v) for v in c.split(",")) for c in a.extra.split(";") if c]
+        base = json.load(open(os.path.join(ROOT, "imagharmony_amd", "tuning.json"))) if extra else None
+        table, report = sweep_shapes(rec, dtype, extra, base)
         with open(os.path.join(a.out, f"tuning_s{a.candidates}.json" if a.candidates > 1 else "tuning.json"), "w") as f:
             json.dump(table, f, indent=0)
         with open(os.path.join(a.out, "sweep_report.json"), "w") as f:
