@@ -400,12 +400,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // consumer never waits on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1
 // has landed" (producers wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt
 // before arriving), after which the producers refill tile i's slot.
+#ifndef WS_LNABL
+#define WS_LNABL 0    // tools only: 1 producers skip the row sums, 2 no statistics hand-over, 8 no LN formula in the epilogue
+#endif
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
 #endif
-template <typename T, int BM, int BN, int S, int NP, bool CONV>
-__global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmParams p) {
-    constexpr int TM = BM / 2, TN = BN / 2;
+// CM x CN consumer waves over the tile; LN = 1: folded LayerNorm, row form.  The row statistics are the PRODUCERS' job:
+// thread t of the producer group owns token row t of the tile and adds up its 128 bytes of every landed K tile straight
+// from LDS (eight ds_read_b128, chunk order rotated by the lane against bank conflicts, v_dot2c sums), which keeps every
+// VALU instruction out of the waves that feed the MFMA pipe; mean / rstd reach the consumers through LDS after the loop.
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
+__global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
+    constexpr int NC = CM * CN;
+    constexpr int TM = BM / CM, TN = BN / CN;
+    static_assert(LN == 0 || (!CONV && 64 * NP >= BM), "one producer thread per token row");
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
     constexpr int NI = (BM + BN) / 8;              // ... and in total
@@ -431,9 +440,9 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmPar
     const int kt1 = min(nkt, kt0 + per);
     const int nt = max(0, kt1 - kt0);
 
-    if (wave >= 4) {
+    if (wave >= NC) {
         // ------------------------------------------------------------------ producer
-        const int pw = wave - 4;
+        const int pw = wave - NC;
         const unsigned char* zero = g_zero_page;
         const unsigned char* base[LP];
         int step[LP];
@@ -503,19 +512,43 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmPar
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = S - 1;                                     // slot of tile i + S - 1
+        int cslot = 0;                                        // slot of tile i
+        const int srow = pw * 64 + lane;                      // LN: the token row this thread sums
+        float rs = 0.f, rq = 0.f;
         for (int i = 0; i < nt; ++i) {
             if (i + S - 1 < nt) issue(slot, kt0 + i + S - 1); // the slot tile i - 1 was read from
+            if constexpr (LN == 1) {
+                if (srow < BM && !(WS_LNABL & 1)) {
+                    const unsigned char* xr = smem + cslot * STAGE + srow * GEMM_ROW_BYTES;
+                    v8 f[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + lane) & 7) << 4));
+                    float s2 = 0.f, q2 = 0.f;                 // two independent chains of v_dot2c
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2) { frag_stats(f[c], rs, rq); frag_stats(f[c + 1], s2, q2); }
+                    rs += s2; rq += q2;
+                }
+                if (i == nt - 1 && srow < BM) {               // published with the hand-over of the last K tile, into
+                    const float invk = 1.0f / (float)p.K;     // the slot of tile nt - 2 (read out one hand-over ago)
+                    const float mean = rs * invk;
+                    float* ex = (float*)(smem + (cslot == 0 ? S - 1 : cslot - 1) * STAGE);
+                    ex[srow * 2 + 0] = mean;
+                    ex[srow * 2 + 1] = rsqrtf(fmaxf(rq * invk - mean * mean, 0.f) + p.ln_eps);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (++cslot == S) cslot = 0;
+            }
             if (i + S <= nt) wait_vmcnt<(S - 2) * LP>();      // tile i + 1 has landed
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++slot == S) slot = 0;
         }
-        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 256, 64 * NP);
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 64 * NC, 64 * NP);
         return;
     }
 
     // ---------------------------------------------------------------------- consumer
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CN, wn = wave % CN;
     int xoff[2], woff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -586,6 +619,24 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmPar
     if (nt > 0) mm(K1);
 
     const int nb = n0 + wn * TN + (lane >> 4) * 4 * FN;
+    // s_n, c_n (folded LayerNorm) or the bias of this lane's columns: fetched once, ahead of the stores (EpiPre; the LN
+    // instantiations are at the register cap of twelve waves per CU and let the epilogue fetch the bias per row)
+    float lnpre[8 * FN];
+    const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
+    EpiPre<4 * FN> pre;
+    pre.ok = !p.rowadd && !p.residual && p.splits == 1 && epilogue_fast<T, 4 * FN>(p, nb);
+    if (pre.ok && p.bias) ldv<T, 4 * FN>((const T*)p.bias + nb, pre.bias);
+    LnArgs<4 * FN> ln;
+    float st_s[FM], st_q[FM];
+    if constexpr (LN == 1) {                       // mean / rstd of the tile's rows, published by the producers (see above)
+        const float* ex = (const float*)(smem + ((nt + S - 2) % S) * STAGE);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * TM + i * 16 + (lane & 15);
+            st_s[i] = ex[r * 2 + 0];
+            st_q[i] = ex[r * 2 + 1];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
@@ -605,25 +656,34 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void gemm_ws_kernel(const GemmPar
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            epilogue_store<T, FN>(p, v, m, nb);
+            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre);
         }
     }
 }
 
-template <typename T, int BM, int BN, int S, int NP, bool CONV>
-static int launch_ws(const GemmParams& p, hipStream_t stream) {
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
+static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
-    auto kern = gemm_ws_kernel<T, BM, BN, S, NP, CONV>;
+    auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * (4 + NP)), smem, stream, q);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * (CM * CN + NP)), smem, stream, q);
     return check_launch("gemm_ws_kernel");
+}
+
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV>
+static int launch_ws(const GemmParams& p, hipStream_t stream) {
+    if constexpr (!CONV && CN == 2) {
+        if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1>(p, stream);
+    }
+    return launch_ws_ln<T, BM, BN, CM, CN, S, NP, CONV, 0>(p, stream);
 }
 
 template <typename T, int BM, int BN, bool CONV>
@@ -679,10 +739,12 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
     // wave-specialised 64 x 160, 4-stage ring, four consumer waves + two (1464) / four (2464) producer waves
     // (a fifth stage measured no different)
-    if (bm == 1464 && bn == 160) return launch_ws<T, 64, 160, 4, 2, CONV>(p, stream);
-    if (bm == 2464 && bn == 160) return launch_ws<T, 64, 160, 4, 4, CONV>(p, stream);   // four producer waves
-    if (bm == 24128 && bn == 160) return launch_ws<T, 128, 160, 4, 4, CONV>(p, stream);  // M = 8192, N = 640: 256 tiles
-    if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 4, 4, CONV>(p, stream);
+    if (bm == 1464 && bn == 160) return launch_ws<T, 64, 160, 2, 2, 4, 2, CONV>(p, stream);
+    if (bm == 2464 && bn == 160) return launch_ws<T, 64, 160, 2, 2, 4, 4, CONV>(p, stream);   // four producer waves
+    if (bm == 24128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 4, 4, CONV>(p, stream);  // M = 8192, N = 640: 256 tiles
+    if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 2, 2, 4, 4, CONV>(p, stream);
+    // 256 x 160, eight consumer waves (4 x 2, 64 x 80 each) + four producers, 3 stages (156 KB): N = 10240 -> 512 tiles
+    if (bm == 23256 && bn == 160) return launch_ws<T, 256, 160, 4, 2, 3, 4, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);
     if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
     set_error("gemm_ring: unsupported variant %dx%d", bm, bn);

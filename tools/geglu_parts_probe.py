@@ -16,7 +16,10 @@ wf = torch.randn(N, K, device=DEV) * K ** -0.5
 norm = torch.nn.LayerNorm(K, eps=1e-5)
 wg, s, c = fold_ln(wf, norm, ctx)
 bias = torch.randn(N, device=DEV).to(dtype)
-for cfg in [(128, 128, 1), (9128, 320, 1), (9256, 320, 1)]:
+CFGS = [(128, 128, 1), (9128, 320, 1), (23256, 160, 1), (24128, 160, 1), (24128, 128, 1)]
+if os.environ.get('GEGLU_CFG'):
+    CFGS = [tuple(int(v) for v in os.environ['GEGLU_CFG'].split(','))]
+for cfg in CFGS:
     line = f"{cfg[0]}x{cfg[1]}:"
     for name, kw in [("plain", dict()), ("bias", dict(bias=bias)), ("GEGLU", dict(flags=L.GF_GEGLU, bias=bias)),
                      ("LN", dict(flags=L.GF_LN_ROW, ln=(s, c, 1e-5), bias=bias)),

@@ -9,11 +9,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "run":
     L.load()
     DEV = "cuda:0"; dtype = torch.bfloat16
     line = ""
-    for (M, N, K) in [(2048, 1280, 1280), (2048, 1280, 5120)]:
+    cfg = tuple(int(v) for v in os.environ.get("WS_CFG", "2464,160,1").split(","))
+    shapes = [(2048, 1280, 1280), (2048, 1280, 5120)] if cfg[0] != 23256 else [(2048, 10240, 1280), (2048, 10240, 5120)]
+    for (M, N, K) in shapes:
         x = torch.randn(M, K, device=DEV).to(dtype); w = (torch.randn(N, K, device=DEV) * K ** -0.5).to(dtype)
         out = torch.empty(M, N, device=DEV, dtype=dtype)
         for kw in ({}, dict(ldx=0, ldw=0)):
-            us = graph_time(lambda c: c.gemm(x, w, out=out, cfg=(2464, 160, 1), **kw), dtype, n=20, reps=3) * 1e3
+            us = graph_time(lambda c: c.gemm(x, w, out=out, cfg=cfg, **kw), dtype, n=20, reps=3) * 1e3
             line += f"  K={K}{' hot' if kw else ''} {us:6.1f}us"
     print(line, flush=True)
 else:
