@@ -84,7 +84,8 @@ typedef struct imh_gemm_args {
      * token row are computed INSIDE the kernel's K loop from the operand fragments the MFMAs consume (fp32 sum and
      * sum of squares over K), so no statistics buffer exists.  ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k
      * W[.,k] (fp32; row form: per output column n, column form: per output row m).  Plain 64/128 tiles (both
-     * forms) or the ping-pong variants bm = 8256 / 9128 / 9256 (row form); splits == 1, conv == 0. */
+     * forms), the ping-pong variants bm = 8256 / 9128 / 9256 or the wave-specialised ones 1464 / 2464 / 24128 / 23256
+     * (row form; there the producer waves sum the rows from LDS); splits == 1, conv == 0. */
     const float* ln_s;
     const float* ln_c;
     float ln_eps;
@@ -98,7 +99,9 @@ typedef struct imh_gemm_args {
     int32_t conv;
     /* tile variant (0 = heuristic): bm in {64, 128} x bn in {64, 128}: two-stage tiles (gemm.hip); 256 x {128, 256}:
      * 8-wave rings; 3064 x 64 / 3128 x 128: KG2; 4064 / 4128 / 5064: small-tile rings; 5258 x 320, 6128 x 320: the
-     * 256 x 320 / 128 x 320 exact tilings; 8256 x 256, 9128 x 320, 9256 x 320: ping-pong kernels (gemm_pp.hip). */
+     * 256 x 320 / 128 x 320 exact tilings; 8256 x 256, 9128 x 320, 9256 x 320: ping-pong kernels (gemm_pp.hip);
+     * 1464 / 2464 x 160, 24128 x 160 / 128, 23256 x 160: wave-specialised kernel (producer + consumer waves,
+     * gemm_ring.hip); 7128 / 7564 x 320 / 160: LDS-halo conv3x3 (conv_halo.hip, stride 1). */
     int32_t bm, bn;
     /* cache hint: the NEXT launch's weight matrix; exiting workgroups touch it (HBM -> L2 / Infinity Cache) */
     const void* pf_ptr;
