@@ -406,22 +406,25 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
 #endif
-// CM x CN consumer waves over the tile; LN = 1: folded LayerNorm, row form.  The row statistics are the PRODUCERS' job:
-// thread t of the producer group owns token row t of the tile and adds up its 128 bytes of every landed K tile straight
-// from LDS (eight ds_read_b128, chunk order rotated by the lane against bank conflicts, v_dot2c sums), which keeps every
-// VALU instruction out of the waves that feed the MFMA pipe; mean / rstd reach the consumers through LDS after the loop.
+// CM x CN consumer waves over the tile; LN = 1: folded LayerNorm, row form.  The producer group then splits once more:
+// two LOADER waves run the LDS-DMA ring and the other NP - 2 are STATISTICS waves -- thread t owns token rows t, t + TS, ...
+// of the tile and adds up their 128 bytes of every landed K tile straight from LDS (v_dot2c sums), in parallel with the
+// loaders' issue and with every VALU instruction kept out of the waves that feed the MFMA pipe; mean / rstd reach the
+// consumers through a dead ring slot with the last hand-over.  (Summing in the loader waves themselves put ~600 cycles
+// per K tile on the loaders' critical path: +8..10 us on the ff.net.0 launch.)
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
 __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
     constexpr int NC = CM * CN;
     constexpr int TM = BM / CM, TN = BN / CN;
-    static_assert(LN == 0 || (!CONV && 64 * NP >= BM), "one producer thread per token row");
+    static_assert(LN == 0 || (!CONV && NP >= 3), "LN: two loader waves + NP - 2 statistics waves");
+    constexpr int NL = LN == 1 ? 2 : NP;           // loader waves; with LN the other producers only sum rows
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
     constexpr int NI = (BM + BN) / 8;              // ... and in total
-    constexpr int LP = NI / NP, KX = NIX / NP;     // per producer wave
+    constexpr int LP = NI / NL, KX = NIX / NL;     // per loader wave
     constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
     constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;
-    static_assert(NI % NP == 0 && NIX % NP == 0, "instructions split evenly between the producers");
+    static_assert(NI % NL == 0 && NIX % NL == 0, "instructions split evenly between the loaders");
     static_assert((S - 2) * LP <= 63, "vmcnt range");
     static_assert(TN % (4 * FN) == 0, "weight fragment rows");
     typedef typename Vec<T>::v8 v8;
@@ -443,6 +446,55 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
     if (wave >= NC) {
         // ------------------------------------------------------------------ producer
         const int pw = wave - NC;
+        if constexpr (LN == 1) {
+            if (pw >= NL) {
+                // ---------------------------------------------------------- statistics wave (LN): thread t sums token
+                // rows t, t + TS, ... of every landed K tile straight from LDS (eight ds_read_b128 per row, chunk order
+                // rotated by the lane against bank conflicts; v_dot2c), beside the loaders' LDS-DMA issue
+                constexpr int TS = 64 * (NP - NL), RPT = (BM + TS - 1) / TS;
+                const int t = (pw - NL) * 64 + lane;
+                float rs[RPT], rq[RPT];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) { rs[k] = 0.f; rq[k] = 0.f; }
+                __builtin_amdgcn_s_barrier();                 // tile 0 has landed
+                asm volatile("" ::: "memory");
+                int cslot = 0;
+                for (int i = 0; i < nt; ++i) {
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const int row = t + k * TS;
+                        if (row < BM && !(WS_LNABL & 1)) {
+                            const unsigned char* xr = smem + cslot * STAGE + row * GEMM_ROW_BYTES;
+                            v8 f[8];
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + lane) & 7) << 4));
+                            float s2 = 0.f, q2 = 0.f;         // two independent chains of v_dot2c
+#pragma unroll
+                            for (int c = 0; c < 8; c += 2) { frag_stats(f[c], rs[k], rq[k]); frag_stats(f[c + 1], s2, q2); }
+                            rs[k] += s2; rq[k] += q2;
+                        }
+                    }
+                    if (i == nt - 1) {                        // published with the hand-over of the last K tile, into the
+                        const float invk = 1.0f / (float)p.K; // slot of tile nt - 2 (read out one hand-over ago)
+                        float* ex = (float*)(smem + (cslot == 0 ? S - 1 : cslot - 1) * STAGE);
+#pragma unroll
+                        for (int k = 0; k < RPT; ++k) {
+                            const int row = t + k * TS;
+                            const float mean = rs[k] * invk;
+                            if (row < BM) {
+                                ex[row * 2 + 0] = mean;
+                                ex[row * 2 + 1] = rsqrtf(fmaxf(rq[k] * invk - mean * mean, 0.f) + p.ln_eps);
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (++cslot == S) cslot = 0;
+                }
+                return;
+            }
+        }
         const unsigned char* zero = g_zero_page;
         const unsigned char* base[LP];
         int step[LP];
@@ -450,7 +502,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
         bool cvalid[KX > 0 ? KX : 1];
 #pragma unroll
         for (int k = 0; k < LP; ++k) {
-            const int r = (k * NP + pw) * 8 + (lane >> 3);    // row of the stage: token rows, then weight rows
+            const int r = (k * NL + pw) * 8 + (lane >> 3);    // row of the stage: token rows, then weight rows
             if (k < KX) {
                 const int c = stage_chunk_x(r, lane);
                 const int m = m0 + r;
@@ -487,9 +539,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             }
 #pragma unroll
             for (int k = 0; k < LP; ++k) {
-                unsigned char* dst = st + (k * NP + pw) * 8 * GEMM_ROW_BYTES;
+                unsigned char* dst = st + (k * NL + pw) * 8 * GEMM_ROW_BYTES;
                 if (CONV && k < KX) {
-                    const int r = (k * NP + pw) * 8 + (lane >> 3);
+                    const int r = (k * NL + pw) * 8 + (lane >> 3);
                     const int c = stage_chunk_x(r, lane);
                     const int Hv = p.H << p.up, Wv = p.Wd << p.up;
                     const int iy = coy[k] * p.stride + ky - 1;
@@ -512,38 +564,14 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = S - 1;                                     // slot of tile i + S - 1
-        int cslot = 0;                                        // slot of tile i
-        const int srow = pw * 64 + lane;                      // LN: the token row this thread sums
-        float rs = 0.f, rq = 0.f;
         for (int i = 0; i < nt; ++i) {
             if (i + S - 1 < nt) issue(slot, kt0 + i + S - 1); // the slot tile i - 1 was read from
-            if constexpr (LN == 1) {
-                if (srow < BM && !(WS_LNABL & 1)) {
-                    const unsigned char* xr = smem + cslot * STAGE + srow * GEMM_ROW_BYTES;
-                    v8 f[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + lane) & 7) << 4));
-                    float s2 = 0.f, q2 = 0.f;                 // two independent chains of v_dot2c
-#pragma unroll
-                    for (int c = 0; c < 8; c += 2) { frag_stats(f[c], rs, rq); frag_stats(f[c + 1], s2, q2); }
-                    rs += s2; rq += q2;
-                }
-                if (i == nt - 1 && srow < BM) {               // published with the hand-over of the last K tile, into
-                    const float invk = 1.0f / (float)p.K;     // the slot of tile nt - 2 (read out one hand-over ago)
-                    const float mean = rs * invk;
-                    float* ex = (float*)(smem + (cslot == 0 ? S - 1 : cslot - 1) * STAGE);
-                    ex[srow * 2 + 0] = mean;
-                    ex[srow * 2 + 1] = rsqrtf(fmaxf(rq * invk - mean * mean, 0.f) + p.ln_eps);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (++cslot == S) cslot = 0;
-            }
             if (i + S <= nt) wait_vmcnt<(S - 2) * LP>();      // tile i + 1 has landed
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++slot == S) slot = 0;
         }
-        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 64 * NC, 64 * NP);
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 64 * NC, 64 * NL);
         return;
     }
 
@@ -637,6 +665,41 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             st_q[i] = ex[r * 2 + 1];
         }
     }
+    if constexpr (LN == 1) {
+        // the transformer blocks' launches (ff.net.0: LN + bias + GEGLU; to_q / to_k: LN only) take a lean epilogue: whole
+        // 4*FN-column run in range, vector-aligned output, no row-add / residual / activation -- operands fetched once
+        // above, then per row the LN formula, the GEGLU product and ONE store
+        if ((p.flags & ~(GF_LN_ROW | GF_GEGLU)) == 0 && pre.ok && have_pre && !(WS_LNABL & 8)) {
+            constexpr int NV = 4 * FN;
+            const bool geglu = p.flags & GF_GEGLU;
+            if (!p.bias) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) pre.bias[q] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                if (m >= p.M) continue;
+                float v[NV];
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = j * 4 + r;
+                        v[q] = fma_nopk(st_q[i], fma_nopk(-st_s[i], lnpre[q], acc[i][j][r]), lnpre[NV + q]) + pre.bias[q];
+                    }
+                if (geglu) {
+                    float o[NV / 2];
+#pragma unroll
+                    for (int q = 0; q < NV / 2; ++q) o[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
+                    stv<T, NV / 2>((T*)p.Y + (size_t)m * p.ldy + (nb >> 1), o);
+                } else {
+                    stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
@@ -680,7 +743,7 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV>
 static int launch_ws(const GemmParams& p, hipStream_t stream) {
-    if constexpr (!CONV && CN == 2) {
+    if constexpr (!CONV && NP >= 3) {
         if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1>(p, stream);
     }
     return launch_ws_ln<T, BM, BN, CM, CN, S, NP, CONV, 0>(p, stream);

@@ -179,7 +179,7 @@ class Ctx:
         bm, bn, sp = cfg or self._config(M, N, K, 0, flags)
         if _args_only:
             sp = 1
-        if ln is not None and cfg is None and (sp > 1 or (bm >= 256 and bm not in (8256, 9128, 9256, 1464, 2464, 24128, 23256))):   # the in-loop statistics live in the plain 2x2-wave tiles only
+        if ln is not None and cfg is None and (sp > 1 or (bm >= 256 and bm not in (8256, 9128, 9256, 2464, 24128, 23256))):   # the in-loop statistics live in the plain 2x2-wave tiles only
             # (an explicit cfg is passed through: the C side rejects split-K / ring variants for the folded form)
             bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
         a = L.GemmArgs()
