@@ -700,6 +700,40 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             return;
         }
     }
+    if constexpr (LN == 0 && NC + NP <= 8) {
+        // the residual-add launches (to_out, ff.out, proj_out: bias + residual, nothing else) likewise: the residual rows of
+        // ALL of the lane's fragments are fetched before the first store -- the generic epilogue's per-row loads queue behind
+        // the previous row's stores (possible aliasing as far as the compiler knows; in place, Y == residual, is fine here:
+        // every element is read before its own store, by the same lane)
+        if (p.flags == 0 && !p.rowadd && p.residual && p.splits == 1 && epilogue_fast<T, 4 * FN>(p, nb)) {
+            constexpr int NV = 4 * FN;
+            float bs[NV], rr[FM][NV];
+            if (p.bias) ldv<T, NV>((const T*)p.bias + nb, bs);
+            else {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) bs[q] = 0.f;
+            }
+            bool ok[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                ok[i] = m < p.M;
+                if (ok[i]) ldv<T, NV>((const T*)p.residual + (size_t)m * p.ldr + nb, rr[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if (!ok[i]) continue;
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                float v[NV];
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bs[j * 4 + r] + rr[i][j * 4 + r];
+                stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
