@@ -450,7 +450,8 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             if (pw >= NL) {
                 // ---------------------------------------------------------- statistics wave (LN): thread t sums token
                 // rows t, t + TS, ... of every landed K tile straight from LDS (eight ds_read_b128 per row, chunk order
-                // rotated by the lane against bank conflicts; v_dot2c), beside the loaders' LDS-DMA issue
+                // rotated by lane >> 1: conflict-free under the ds_read_b128 lane groups, tests/emu; v_dot2c), beside the
+                // loaders' LDS-DMA issue
                 constexpr int TS = 64 * (NP - NL), RPT = (BM + TS - 1) / TS;
                 const int t = (pw - NL) * 64 + lane;
                 float rs[RPT], rq[RPT];
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
                             const unsigned char* xr = smem + cslot * STAGE + row * GEMM_ROW_BYTES;
                             v8 f[8];
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + lane) & 7) << 4));
+                            for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + (lane >> 1)) & 7) << 4));
                             float s2 = 0.f, q2 = 0.f;         // two independent chains of v_dot2c
 #pragma unroll
                             for (int c = 0; c < 8; c += 2) { frag_stats(f[c], rs[k], rq[k]); frag_stats(f[c + 1], s2, q2); }

@@ -100,6 +100,101 @@ static int test_gemm(int BM, int BN, int K, bool vt_perm) {
     return bad;
 }
 
+// ---- wave-specialised GEMM (gemm_ws_kernel, gemm_ring.hip): NL loader waves stage rows q*8 + (lane>>3) of the concatenated
+// [token rows; weight rows] stage (q = k*NL + pw), CM x CN consumer waves read FM + FN fragments per k step; the statistics
+// waves read token row r chunk ((c + lane) & 7).  Checks: every stage byte written exactly once, product == matmul, the
+// row sums == plain sums, and the ds_read_b128 bank model (lane groups of the guide's table) is conflict-free for the
+// fragment reads.
+static int ds_read_b128_conflicts(const int addr[64]) {
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    int extra = 0;
+    for (auto& g : groups) {
+        int cnt[64] = {};
+        for (int l : g) for (int d = 0; d < 4; ++d) ++cnt[((addr[l] >> 2) + d) & 63];
+        int mx = 0;
+        for (int b = 0; b < 64; ++b) mx = std::max(mx, cnt[b]);
+        extra += mx - 1;
+    }
+    return extra;
+}
+
+static int test_gemm_ws(int BM, int BN, int CM, int CN, int NL, int K) {
+    const int TM = BM / CM, TN = BN / CN, FM = TM / 16, FN = TN / 16, NI = (BM + BN) / 8, LP = NI / NL, NC = CM * CN;
+    const int XT = BM * 128, STAGE = (BM + BN) * 128;
+    std::vector<float> X(BM * K), W(BN * K), Y(BM * BN, NAN), R(BM * BN, 0.f);
+    for (auto& v : X) v = frand();
+    for (auto& v : W) v = frand();
+    for (int m = 0; m < BM; ++m) for (int n = 0; n < BN; ++n) { float s = 0; for (int k = 0; k < K; ++k) s += X[m * K + k] * W[n * K + k]; R[m * BN + n] = s; }
+    std::vector<std::vector<float>> acc(NC * 64, std::vector<float>(FM * FN * 4, 0.f));
+    std::vector<double> rs(BM, 0.0), rq(BM, 0.0);
+    int bad = 0, conflicts = 0;
+    for (int kt = 0; kt < K / 64; ++kt) {
+        Lds st(STAGE);
+        std::vector<int> written(STAGE / 16, 0);
+        for (int pw = 0; pw < NL; ++pw) for (int k = 0; k < LP; ++k) for (int lane = 0; lane < 64; ++lane) {
+            const int q = k * NL + pw, r = q * 8 + (lane >> 3);
+            const int off = q * 8 * 128 + lane * 16;                      // M0 = stage + q*8*128, + lane*16
+            ++written[off / 16];
+            float* d = st.at(off);
+            if (r < BM) { const int c = stage_chunk_x(r, lane); for (int e = 0; e < 8; ++e) d[e] = X[r * K + kt * 64 + c * 8 + e]; }
+            else { const int row = r - BM, c = stage_chunk_w(row, lane, FN); for (int e = 0; e < 8; ++e) d[e] = W[row * K + kt * 64 + c * 8 + e]; }
+        }
+        for (int w : written) if (w != 1) ++bad;
+        for (int wave = 0; wave < NC; ++wave) {
+            const int wm = wave / CN, wn = wave % CN;
+            for (int kk = 0; kk < 2; ++kk) {
+                int xo[64], wo[64];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int xr = wm * TM + (lane & 15), wr = wn * TN + w_frag_row(lane & 15, 0, FN);
+                    xo[lane] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
+                    wo[lane] = XT + tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+                }
+                for (int i = 0; i < FM; ++i) { int a[64]; for (int l = 0; l < 64; ++l) a[l] = xo[l] + i * 16 * 128; conflicts += ds_read_b128_conflicts(a); }
+                for (int j = 0; j < FN; ++j) { int a[64]; for (int l = 0; l < 64; ++l) a[l] = wo[l] + j * 4 * 128; conflicts += ds_read_b128_conflicts(a); }
+                for (int i = 0; i < FM; ++i) for (int j = 0; j < FN; ++j) {
+                    float a[64][8], b[64][8], c4[64][4];
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const float* xf = st.at(xo[lane] + i * 16 * 128);
+                        const float* wf = st.at(wo[lane] + j * 4 * 128);
+                        for (int e = 0; e < 8; ++e) { a[lane][e] = wf[e]; b[lane][e] = xf[e]; }
+                        for (int r = 0; r < 4; ++r) c4[lane][r] = acc[wave * 64 + lane][(i * FN + j) * 4 + r];
+                    }
+                    mfma16(a, b, c4);
+                    for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 4; ++r) acc[wave * 64 + lane][(i * FN + j) * 4 + r] = c4[lane][r];
+                }
+            }
+        }
+        for (int row = 0; row < BM; ++row) {                              // statistics thread of this row, lane = row & 63
+            const int lane = row & 63;
+            for (int c = 0; c < 8; ++c) {
+                const float* f = st.at(row * 128 + (((c + (lane >> 1)) & 7) << 4));
+                for (int e = 0; e < 8; ++e) { rs[row] += f[e]; rq[row] += (double)f[e] * f[e]; }
+            }
+        }
+    }
+    for (int wave = 0; wave < NC; ++wave) for (int lane = 0; lane < 64; ++lane) {
+        const int wm = wave / CN, wn = wave % CN;
+        for (int i = 0; i < FM; ++i) {
+            const int m = wm * TM + i * 16 + (lane & 15), nb = wn * TN + (lane >> 4) * 4 * FN;
+            for (int j = 0; j < FN; ++j) for (int r = 0; r < 4; ++r) Y[m * BN + nb + j * 4 + r] = acc[wave * 64 + lane][(i * FN + j) * 4 + r];
+        }
+    }
+    for (int i = 0; i < BM * BN; ++i) if (!(Y[i] == R[i])) ++bad;
+    for (int m = 0; m < BM; ++m) {
+        double s = 0, q = 0;
+        for (int k = 0; k < K; ++k) { s += X[m * K + k]; q += (double)X[m * K + k] * X[m * K + k]; }
+        if (s != rs[m] || q != rq[m]) ++bad;
+    }
+    int stat_extra = 0;                                                   // the row-per-lane statistics reads (lane = row & 63)
+    for (int c = 0; c < 8; ++c) { int a[64]; for (int l = 0; l < 64; ++l) a[l] = l * 128 + (((c + (l >> 1)) & 7) << 4); stat_extra += ds_read_b128_conflicts(a); }
+    printf("gemm_ws %dx%d consumers %dx%d loaders %d K=%d: %s (%d mismatches, %d extra LDS cycles on fragment reads, %d on the "
+           "statistics reads)\n", BM, BN, CM, CN, NL, K, (bad || conflicts || stat_extra) ? "FAIL" : "ok", bad, conflicts, stat_extra);
+    return bad + conflicts + stat_extra;
+}
+
 static int test_attention(int Lk_valid, int Lk_pad) {
     const int D = 64, NQ = 128;
     std::vector<float> Q(NQ * D), Kx(Lk_pad * D, 0.f), V(Lk_pad * D, 0.f), VT(D * Lk_pad, 0.f), O(NQ * D, NAN), R(NQ * D);
@@ -259,6 +354,12 @@ int main() {
     for (int bm : {128, 64}) for (int bn : {128, 64}) bad += test_gemm(bm, bn, 128, false);
     bad += test_gemm(128, 128, 64, true);
     bad += test_gemm(64, 128, 64, true);
+    bad += test_gemm_ws(64, 160, 2, 2, 2, 128);     // 1464: two loaders
+    bad += test_gemm_ws(64, 160, 2, 2, 4, 128);     // 2464
+    bad += test_gemm_ws(128, 160, 2, 2, 4, 128);    // 24128 x 160
+    bad += test_gemm_ws(128, 128, 2, 2, 4, 64);     // 24128 x 128
+    bad += test_gemm_ws(256, 160, 4, 2, 4, 128);    // 23256
+    bad += test_gemm_ws(256, 160, 4, 2, 2, 64);     // 23256 with the folded LayerNorm: two loaders + two statistics waves
     bad += test_attention(64, 64);
     bad += test_attention(128, 128);
     bad += test_attention(77, 128);
