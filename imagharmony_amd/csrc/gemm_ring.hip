@@ -395,13 +395,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // (tools/micro/glds_rate.hip), 448 cycles per K tile against 320 cycles of MFMA time, and a wave that is queued
 // behind that unit with an LDS-DMA instruction cannot issue its MFMAs (tools/hot_probe.py: cache-hot operands
 // change nothing).  So the roles are split: NP producer waves do nothing but issue the LDS-DMA ring (own vmcnt
-// counters, S - 1 tiles ahead), four consumer waves (2 x 2 over the tile) only read fragments and issue MFMAs,
-// with the fragments of tile i + 1 read into a second register set while the MFMAs of tile i run, so that a
-// consumer never waits on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1
-// has landed" (producers wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt
-// before arriving), after which the producers refill tile i's slot.
+// counters, S - 1 tiles ahead), CM x CN consumer waves only read fragments and issue MFMAs, with the fragments of
+// k step kk + 1 read into a second register set while the MFMAs of k step kk run, so that a consumer never waits
+// on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1 has landed" (producers
+// wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt before arriving), after which
+// the producers refill tile i's slot.
 #ifndef WS_LNABL
-#define WS_LNABL 0    // tools only: 1 producers skip the row sums, 2 no statistics hand-over, 8 no LN formula in the epilogue
+#define WS_LNABL 0    // tools only: 1 the statistics waves skip the row sums, 8 generic epilogue without the LN formula
 #endif
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
