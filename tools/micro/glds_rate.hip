@@ -60,7 +60,8 @@ int main() {
     for (int resident = 1; resident >= 0; --resident) {
         for (int wgpc : {1, 2, 4}) {
             const int wgs = 256 * wgpc;
-            // L2-resident: every WG cycles a private 64 KB window (total 16-64 MB over 8 XCD L2s of 4 MB: keep 16 KB windows -> 4-16 MB)
+            // "L2-resident" (label kept for the committed CSV): every WG cycles a private 16 KB window -- which fits the CU's
+            // 32 KB vector L1, so these rows are L1-HIT rates; a true L2 figure needs a window above 32 KB per CU
             const size_t window = resident ? 16 * 1024 : (total / wgs);
             const size_t stride = resident ? 16 * 1024 : (total / wgs);
             const int iters_base = resident ? 4000 : 0;
