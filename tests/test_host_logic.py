@@ -232,3 +232,28 @@ def test_integration_md_gemm_stub_matches_lib_and_header():
     want = list(lib.GemmArgs._fields_)
     assert [f[0] for f in fields] == [w[0] for w in want]
     assert [getattr(C, f[1]) for f in fields] == [w[1] for w in want]       # c_int32 is c_int on this ABI: compare the types
+
+
+def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
+    """tuning.json is written by a sweep on the GPU box; a (bm, bn) pair the C++ dispatch does not list would only fail
+    at launch time there.  The dispatch tables are plain `bm == A && bn == B` chains: read them from the sources."""
+    import json
+    import re
+    csrc = os.path.join(ROOT, "imagharmony_amd", "csrc")
+    known = set()
+    for f in ("gemm.hip", "gemm_ring.hip"):
+        for a, b in re.findall(r"bm == (\d+) && bn == (\d+)", open(os.path.join(csrc, f)).read()):
+            known.add((int(a), int(b)))
+    pp = {8256: 256, 9128: 320, 9256: 320}                         # gemm_pp.hip: one tile shape per code
+    halo = {(7128, 320), (7128, 160), (7564, 320), (7564, 160)}    # conv_halo.hip: patch x couts, stride-1 conv only
+    table = json.load(open(os.path.join(ROOT, "imagharmony_amd", "tuning.json")))
+    assert len(table) >= 30
+    for key, (bm, bn, splits) in table.items():
+        M, N, K, conv = (int(v) for v in key.split(","))
+        assert splits >= 1 and K % 64 == 0, key
+        if (bm, bn) in halo:
+            assert conv == 1, key
+        elif bm in pp:
+            assert pp[bm] == bn and conv == 0 and splits == 1, key
+        else:
+            assert (bm, bn) in known, f"{key}: variant {bm} x {bn} is not in the dispatch tables"
