@@ -257,3 +257,24 @@ def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
             assert pp[bm] == bn and conv == 0 and splits == 1, key
         else:
             assert (bm, bn) in known, f"{key}: variant {bm} x {bn} is not in the dispatch tables"
+
+
+def test_folded_layernorm_launches_only_get_variants_that_implement_it():
+    """host logic of Ctx.gemm: a tuning-table variant without the folded-LayerNorm statistics (rings, KG2, the
+    two-producer wave-specialised 1464) is replaced by a plain tile when the launch carries ln=..., the variants that
+    have them (plain tiles, ping-pong, the four-producer wave-specialised ones) are kept, an explicit cfg is passed through"""
+    from imagharmony_amd import lib as L
+    from imagharmony_amd.ctx import Ctx
+    ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
+    M, N, K = 2048, 1280, 2560
+    x, w = torch.zeros(M, K, dtype=torch.bfloat16), torch.zeros(N, K, dtype=torch.bfloat16)
+    s, c = torch.zeros(N), torch.zeros(N)
+    for table, want in (((1464, 160, 1), (64, 64)), ((256, 256, 1), (64, 64)), ((3128, 128, 1), (64, 64)), ((64, 128, 2), (64, 64)),
+                        ((2464, 160, 1), (2464, 160)), ((23256, 160, 1), (23256, 160)), ((9128, 320, 1), (9128, 320)), ((64, 64, 1), (64, 64))):
+        ctx.tuning[(M, N, K, 0)] = table
+        a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), _args_only=True)[0]
+        assert (a.bm, a.bn, a.splits) == (*want, 1), (table, a.bm, a.bn, a.splits)
+        a = ctx.gemm(x, w, _args_only=True)[0]                      # without LN the table entry is used as is
+        assert (a.bm, a.bn) == table[:2]
+    a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(1464, 160, 1), _args_only=True)[0]
+    assert (a.bm, a.bn) == (1464, 160)                              # explicit: the C side is the one to refuse it
