@@ -47,9 +47,16 @@ def _b(attn_lin, ctx):
     return b.detach().contiguous()
 
 
+def _vkey(*tensors):
+    """cache key of derived (packed / folded) weights: storage address AND in-place version counter of every source tensor,
+    so load_state_dict / LoRA fuse / weight.copy_ after the first forward rebuild the derived copy instead of leaving a
+    stale one behind (the address alone does not change on an in-place update)"""
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+
+
 def _packed_qk(attn, ctx):
     """[Wq; Wk] stacked so Q and K of a self-attention layer come out of ONE GEMM; cached on the module."""
-    key = (attn.to_q.weight.data_ptr(), attn.to_k.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    key = (_vkey(attn.to_q.weight, attn.to_k.weight), ctx.dtype, str(ctx.device))
     cached = getattr(attn, "_imh_qk", None)
     if cached is None or cached[0] != key:
         w = torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0).to(device=ctx.device, dtype=ctx.dtype)
@@ -139,7 +146,7 @@ class AttnProcessor2_0(nn.Module):
             g1, g2 = dict(x=x, w=wqk), dict(x=wv, w=x, flags=L.GF_VT_PERM)
         else:
             norm = ln
-            key = (attn.to_q.weight.data_ptr(), attn.to_v.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+            key = (_vkey(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
             fq, fv = _cached(attn, "_imh_ln_qkv", key, lambda: (
                 fold_ln(torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0), norm, ctx),
                 fold_ln(attn.to_v.weight, norm, ctx)))
@@ -240,7 +247,7 @@ class IPAttnProcessor2_0(nn.Module):
             wq, lnq = _w(attn.to_q, ctx), None
         else:       # x is the un-normalised stream; LayerNorm `ln` folded into to_q inside the fused kernel
             norm = ln
-            key = (attn.to_q.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+            key = (_vkey(attn.to_q.weight, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
             fq = _cached(attn, "_imh_ln_q", key, lambda: fold_ln(attn.to_q.weight, norm, ctx))
             wq, lnq = fq[0], (fq[1], fq[2], norm.eps)
         ao = ctx.new(B * L_, C_)

@@ -207,12 +207,12 @@ int attention_small_launch(const SmallAttnParams& p, int dtype, hipStream_t stre
         if (aligned && need <= 150 * 1024) {
             dim3 grid(p.B * p.H);
             if (dtype == IMH_DT_BF16) {
-                static bool a0 = false;
-                if (!a0) { hipFuncSetAttribute((const void*)attn_small_lds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a0 = true; }
+                static DynLdsOnce a0;
+                a0.ensure((const void*)attn_small_lds_kernel<bf16_t>, 150 * 1024);
                 hipLaunchKernelGGL((attn_small_lds_kernel<bf16_t>), grid, dim3(256), need, stream, p, LkP);
             } else {
-                static bool a1 = false;
-                if (!a1) { hipFuncSetAttribute((const void*)attn_small_lds_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a1 = true; }
+                static DynLdsOnce a1;
+                a1.ensure((const void*)attn_small_lds_kernel<f16_t>, 150 * 1024);
                 hipLaunchKernelGGL((attn_small_lds_kernel<f16_t>), grid, dim3(256), need, stream, p, LkP);
             }
             return check_launch("attn_small_lds_kernel");

@@ -196,8 +196,8 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     const int tiles_x = (p.Wo + CH_PW - 1) / CH_PW, tiles_y = (p.Ho + ph - 1) / ph, tiles_n = (p.N + bn - 1) / bn;
     dim3 grid(B * tiles_y * tiles_x * tiles_n);
     const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + 2 * bn * GEMM_ROW_BYTES;
-#define IMH_CH2(TT, FNV, FMV) do { auto kern = conv_halo_kernel<TT, FNV, FMV>; static bool attr_set = false; \
-        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; } \
+#define IMH_CH2(TT, FNV, FMV) do { auto kern = conv_halo_kernel<TT, FNV, FMV>; static DynLdsOnce lds_once; \
+        lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
 #define IMH_CH(TT, FNV) do { if (ph == 8) IMH_CH2(TT, FNV, 2); else IMH_CH2(TT, FNV, 1); } while (0)
     if (dtype == IMH_DT_BF16) { if (bn == 320) IMH_CH(bf16_t, 10); else IMH_CH(bf16_t, 5); }

@@ -488,11 +488,8 @@ static int launch_pq(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, PQ_BM, PQ_BN, &tiles);
     const size_t smem = 2 * (size_t)PQ_BUF;
     auto kern = gemm_pq_kernel<T, LN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
     return check_launch("gemm_pq_kernel");
 }
@@ -763,11 +760,8 @@ static int launch_pr(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, PR_BM, PR_BN, &tiles);
     const size_t smem = 2 * (size_t)PR_BUF;
     auto kern = gemm_pr_kernel<T, LN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
     return check_launch("gemm_pr_kernel");
 }
@@ -784,11 +778,8 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, PP_BM, PP_BN, &tiles);
     const size_t smem = 2 * (size_t)PP_BUF;
     auto kern = gemm_pp_kernel<T, LN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
     return check_launch("gemm_pp_kernel");
 }

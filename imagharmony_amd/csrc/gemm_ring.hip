@@ -767,11 +767,8 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
     auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * (CM * CN + NP)), smem, stream, q);
     return check_launch("gemm_ws_kernel");
 }
@@ -791,11 +788,8 @@ static int launch_kg2(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = 2 * 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
     auto kern = gemm_kg2_kernel<T, BM, BN, CONV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(512), smem, stream, q);
     return check_launch("gemm_kg2_kernel");
 }
@@ -807,11 +801,8 @@ static int launch_ring(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
     auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, S, CONV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * WM * WN), smem, stream, q);
     return check_launch("gemm_ring_kernel");
 }

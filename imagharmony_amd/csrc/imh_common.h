@@ -167,6 +167,18 @@ __device__ __forceinline__ float wave_max(float v) {
 #define IMH_DT_F16 1
 
 namespace imh {
+// Dynamic-LDS opt-in (> 64 KB) is a per-DEVICE function attribute: remember it per device ordinal, so a process that drives a
+// second GPU through the C ABI sets it there as well (a per-process flag would leave every such launch failing on device 1).
+struct DynLdsOnce {
+    unsigned long long done = 0;       // bit d: attribute set on device d (ordinals >= 64: set every time)
+    void ensure(const void* kern, int bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return;
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    }
+};
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 }

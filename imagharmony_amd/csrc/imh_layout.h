@@ -12,7 +12,7 @@
 //                                   D lane l reg r: row (r&3)+8*(r>>2)+4*(l>>5), col l&31
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define IMH_HD __host__ __device__ __forceinline__
 #else
 #define IMH_HD inline

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import lib as L
-from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _w
+from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _vkey, _w
 from .ctx import Ctx
 
 
@@ -79,7 +79,7 @@ class Conv2d(nn.Module):
 
     def packed(self, ctx):
         """[Cout, Cin, k, k] -> [Cout, k*k*Cin] (K index = (ky*k+kx)*Cin + c), cached."""
-        key = (self.weight.data_ptr(), ctx.dtype, str(ctx.device))
+        key = (_vkey(self.weight), ctx.dtype, str(ctx.device))
         c = getattr(self, "_imh_packed", None)
         if c is None or c[0] != key:
             w = self.weight.detach().permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1)
@@ -140,7 +140,7 @@ class GEGLU(nn.Module):
 
     def packed(self, ctx):
         """rows interleaved (value_q, gate_q) so one output tile holds both halves (GF_GEGLU epilogue)."""
-        key = (self.proj.weight.data_ptr(), ctx.dtype, str(ctx.device))
+        key = (_vkey(self.proj.weight, self.proj.bias), ctx.dtype, str(ctx.device))
         c = getattr(self, "_imh_packed", None)
         if c is None or c[0] != key:
             w, b = self.proj.weight.detach(), self.proj.bias.detach()
@@ -156,7 +156,7 @@ class GEGLU(nn.Module):
 def _geglu_packed_ln(self, ctx, norm):
     """GEGLU projection with LayerNorm folded in (see attention_processor.fold_ln), rows interleaved (value, gate)."""
     from .attention_processor import fold_ln
-    key = (self.proj.weight.data_ptr(), norm.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    key = (_vkey(self.proj.weight, self.proj.bias, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
     c = getattr(self, "_imh_packed_ln", None)
     if c is None or c[0] != key:
         wg, s, cc = fold_ln(self.proj.weight, norm, ctx)
@@ -492,7 +492,7 @@ class UNet2DConditionModel(nn.Module):
 
     # ---- packed / stacked weights ----
     def _temb_stack(self, ctx):
-        key = (ctx.dtype, str(ctx.device))
+        key = (_vkey(*[t for r in self.resnets() for t in (r.time_emb_proj.weight, r.time_emb_proj.bias)]), ctx.dtype, str(ctx.device))
         c = getattr(self, "_imh_temb", None)
         if c is None or c[0] != key:
             w = torch.cat([r.time_emb_proj.weight.detach() for r in self.resnets()], 0)

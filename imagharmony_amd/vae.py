@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import lib as L
-from .attention_processor import _b, _w
+from .attention_processor import _b, _vkey, _w
 from .ctx import Ctx
 from .unet import Conv2d, Linear, Norm
 
@@ -169,7 +169,7 @@ class Decoder(nn.Module):
 
 def _pad_conv_in(conv, ctx, cpad=64):
     """conv_in reads a 4-channel latent: zero-pad Cin to 64 so it runs on the implicit-GEMM kernel (K = 9*64)"""
-    key = (conv.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    key = (_vkey(conv.weight), ctx.dtype, str(ctx.device))
     c = getattr(conv, "_imh_padded", None)
     if c is None or c[0] != key:
         w = conv.weight.detach()
@@ -181,7 +181,7 @@ def _pad_conv_in(conv, ctx, cpad=64):
 
 
 def _pad_1x1(conv, ctx, cpad=64):
-    key = (conv.weight.data_ptr(), ctx.dtype, str(ctx.device))
+    key = (_vkey(conv.weight, conv.bias), ctx.dtype, str(ctx.device))
     c = getattr(conv, "_imh_padded", None)
     if c is None or c[0] != key:
         w = conv.weight.detach().view(conv.weight.shape[0], -1)

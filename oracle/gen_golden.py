@@ -28,15 +28,46 @@ ATTN_CASES = {
 }
 
 
+# The shapes the benchmarked forward actually runs (cfg2 = 1024^2, CFG batch 2; cfg4 = batch 8, 16 Resampler
+# tokens).  The full outputs are 5-42 MB each, so a fixture keeps (a) SAMPLE_ROWS seeded token rows per batch element in
+# fp16 and (b) fp32 row sums [B, L] and column sums [B, C] of the WHOLE output: every token and every channel of the
+# reference result is pinned, the sampled rows element by element.
+ATTN_CFG_CASES = {
+    # name: (B, L, C, heads, cross_dim, n_text, T_ip, scale)
+    "cfg2_c1280_L1024_t4": (2, 1024, 1280, 20, 2048, 77, 4, 1.0),
+    "cfg2_c640_L4096_t4": (2, 4096, 640, 10, 2048, 77, 4, 1.0),
+    "cfg4_c1280_L1024_t16_b8": (8, 1024, 1280, 20, 2048, 77, 16, 1.0),
+}
+SAMPLE_ROWS = 48
+
+
+def all_cases():
+    return {**ATTN_CASES, **ATTN_CFG_CASES}
+
+
+def sample_rows(case):
+    """the seeded token rows (sorted, same for every batch element) a cfg-shape fixture stores in full"""
+    b, l = all_cases()[case][:2]
+    g = torch.Generator(device="cpu").manual_seed(977 + l)
+    return torch.randperm(l, generator=g)[:SAMPLE_ROWS].sort().values
+
+
+def compress(case, y):
+    """[B, L, C] fp32 reference output -> what the fixture keeps"""
+    idx = sample_rows(case)
+    return {"rows": y[:, idx].to(torch.float16), "row_sum": y.double().sum(-1).float(), "col_sum": y.double().sum(1).float(),
+            "rms": float(y.double().pow(2).mean().sqrt())}
+
+
 def attn_inputs(case, seed=11):
-    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    b, l, c, h, cd, nt, t, scale = all_cases()[case]
     hs = det_randn((b, l, c), seed + 1)
     ehs = det_randn((b, nt + t, cd), seed + 2)
     return hs, ehs
 
 
 def make_attn(case, cross, seed=11):
-    b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
+    b, l, c, h, cd, nt, t, scale = all_cases()[case]
     a = Attention(c, h, 64, cross_attention_dim=cd if cross else None)
     return det_fill(a, seed + 3, prefix="attn.")
 
@@ -74,6 +105,8 @@ def main():
         torch.save({"case": case, "cfg": ATTN_CASES[case], **out}, os.path.join(OUT, f"attn_{case}.pt"))
         print(case, {k: tuple(v.shape) for k, v in out.items()})
 
+    cfg_shape_fixtures(ref)
+
     # ---- HarmonyAttention + ImageProjModel (train.py:188-266, ip_adapter.py:28-48, :170-176) ----
     with contextlib.redirect_stdout(io.StringIO()):      # reference prints in ctor/forward
         ha = ref.HarmonyAttention(**HA_CFG)
@@ -96,6 +129,28 @@ def main():
         y = r(x)
         torch.save({"out": y, "cfg": cfg, "batch": bsz}, os.path.join(OUT, f"resampler_{name}.pt"))
         print("resampler", name, tuple(y.shape))
+
+
+@torch.no_grad()
+def cfg_shape_fixtures(ref=None):
+    """a1-a3 at the shapes of the benchmarked forward, produced by the VERBATIM reference classes
+    (ip_adapter/attention_processor.py:258-332, :364-465)"""
+    ref = ref or refshim.load()
+    for case, (b, l, c, h, cd, nt, t, scale) in ATTN_CFG_CASES.items():
+        hs, ehs = attn_inputs(case)
+        attn = make_attn(case, cross=True)
+        out = {}
+        for skip in (False, True):
+            p = ref.IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=skip)
+            det_fill(p, 17, prefix="proc.")
+            out[f"ip_skip{int(skip)}"] = compress(case, p(attn, hs, encoder_hidden_states=ehs))
+            if hasattr(p, "attn_map"):
+                del p.attn_map
+        sattn = make_attn(case, cross=False)
+        out["self"] = compress(case, ref.AttnProcessor2_0()(sattn, hs))
+        torch.save({"case": case, "cfg": ATTN_CFG_CASES[case], "sample_rows": sample_rows(case), **out},
+                   os.path.join(OUT, f"attn_{case}.pt"))
+        print(case, {k: tuple(v["rows"].shape) for k, v in out.items()})
 
 
 MLP_CFG = dict(cross_attention_dim=768, clip_embeddings_dim=1280)     # IPAdapterFull on an SD-1.x UNet + ViT-H hidden states

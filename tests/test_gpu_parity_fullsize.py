@@ -19,7 +19,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_rms
+from conftest import record_parity, rel_rms
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -79,10 +79,59 @@ def test_full_sdxl_forward_matches_cpu_oracle(sdxl_pair):
         y = u(x.to(DEV), t, ehs.to(DEV, dtype), added_cond_kwargs={"text_embeds": text.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
         r = rel_rms(y.float().cpu(), ref)
         print(f"full SDXL forward {dtype}: rel-rms vs fp32 CPU oracle {r:.3e} (bound {TOL_FWD[dtype]:.1e})")
+        record_parity(f"unet_forward.cfg2_b2_t4.{str(dtype).split('.')[-1]}", r, TOL_FWD[dtype])
         assert torch.isfinite(y).all() and r < TOL_FWD[dtype], f"{dtype}: rel-rms {r:.3e}"
         if dtype == torch.float16:
             del u
             torch.cuda.empty_cache()
+
+
+def _set_ip_tokens(unet, T):
+    """the image-token count is a slicing attribute of the processors (attention_processor.py:402-406); the to_k_ip / to_v_ip
+    weights do not depend on it, so one weight set serves T = 4 / 16 / 32"""
+    n = 0
+    for p in unet.attn_processors.values():
+        if hasattr(p, "num_tokens"):
+            p.num_tokens = T
+            n += 1
+    assert n == 70
+
+
+# BASELINE.json configs[3] (batch 4 per GPU, 16 Resampler tokens, fp16) and configs[4] (4 PNS candidates per GPU, 2 x 16
+# image tokens, bf16): UNet batch 8 runs OTHER tile variants (M = 8192 x N = 1280 ...) than the batch-2 forward above
+TOL_FWD_B8 = {torch.bfloat16: 5e-2, torch.float16: 8e-3}
+
+
+@pytest.mark.parametrize("dtype,T", [(torch.float16, 16), (torch.bfloat16, 32)])
+def test_full_sdxl_forward_batch8_configs_3_and_4_match_cpu_oracle(sdxl_pair, dtype, T):
+    """full SDXL width, UNet batch 8 (4 stacked candidates x CFG), T image tokens: HIP forward vs the fp32 CPU oracle with
+    identical weights (reference shapes: ip_adapter/ip_adapter.py:392-403 -- 16 queries; :321-322 -- token concat)"""
+    import bench
+    hu, ou = sdxl_pair
+    S = 4
+    pe, ne, po, no = bench.synthetic_conditioning(T)
+    ehs = torch.cat([ne.repeat(S, 1, 1), pe.repeat(S, 1, 1)], 0)
+    text = torch.cat([no.repeat(S, 1), po.repeat(S, 1)], 0)
+    ids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * (2 * S), dtype=torch.float32)
+    z = torch.randn(S, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(17))
+    x = torch.cat([z, z], 0)
+    t = torch.tensor(661.0)
+    _set_ip_tokens(hu, T); _set_ip_tokens(ou, T)
+    try:
+        with torch.no_grad():
+            ref = ou(x, t, ehs, added_cond_kwargs={"text_embeds": text, "time_ids": ids})[0]
+        assert torch.isfinite(ref).all()
+        u = hu if dtype == torch.bfloat16 else _as_fp16(hu)
+        y = u(x.to(DEV), t, ehs.to(DEV, dtype), added_cond_kwargs={"text_embeds": text.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
+        r = rel_rms(y.float().cpu(), ref)
+        per_row = [rel_rms(y[i].float().cpu(), ref[i]) for i in range(2 * S)]
+        print(f"full SDXL forward, batch 8, T={T}, {dtype}: rel-rms vs fp32 CPU oracle {r:.3e} (bound {TOL_FWD_B8[dtype]:.1e}); "
+              "per row " + " ".join(f"{v:.2e}" for v in per_row))
+        record_parity(f"unet_forward.b8_t{T}.{str(dtype).split('.')[-1]}", r, TOL_FWD_B8[dtype], per_row=per_row)
+        assert torch.isfinite(y).all() and r < TOL_FWD_B8[dtype], f"{dtype}: rel-rms {r:.3e}"
+        assert max(per_row) < 1.5 * TOL_FWD_B8[dtype]
+    finally:
+        _set_ip_tokens(hu, 4); _set_ip_tokens(ou, 4)
 
 
 def _as_fp16(hu):
@@ -113,6 +162,7 @@ def test_configs0_512_ten_step_trajectory_matches_cpu_oracle(sdxl_pair):
     per_step = [rel_rms(g, r) for g, r in zip(got, trace)]
     r = rel_rms(out.float().cpu(), ref)
     print("configs[0] 512^2 x 10 DDIM steps, bf16: per-step rel-rms " + " ".join(f"{v:.2e}" for v in per_step) + f"; final {r:.3e}")
+    record_parity("trajectory.configs0_512_10steps.bfloat16", r, TOL_TRAJ10[torch.bfloat16], per_step=per_step)
     assert len(got) == 10 and torch.isfinite(out).all()
     assert r < TOL_TRAJ10[torch.bfloat16], f"final rel-rms {r:.3e}"
 
@@ -124,6 +174,7 @@ def test_thirty_step_trajectory_reduced_width(dtype):
     out, ref = denoise_pair(DEV, dtype, steps=30, hw=32, guidance=5.0)
     r = rel_rms(out, ref)
     print(f"30-step DDIM trajectory (reduced width) {dtype}: rel-rms {r:.3e} (bound {TOL_TRAJ30[dtype]:.1e})")
+    record_parity(f"trajectory.reduced_width_30steps.{str(dtype).split('.')[-1]}", r, TOL_TRAJ30[dtype])
     assert torch.isfinite(out).all() and r < TOL_TRAJ30[dtype], r
 
 

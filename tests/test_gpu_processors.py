@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_rms
+from conftest import GOLDEN, record_parity, rel_rms
 from oracle.detfill import det_fill
 from oracle.gen_golden import ATTN_CASES, attn_inputs, make_attn
 
@@ -30,11 +30,39 @@ def test_ip_processor_matches_reference_golden(case, dtype):
         y = p(attn, hs, encoder_hidden_states=ehs)
         assert y.shape == hs.shape and y.dtype == dtype
         r = rel_rms(y.float().cpu(), g[f"ip_skip{int(skip)}"])
+        record_parity(f"processor.{case}.{str(dtype).split('.')[-1]}.ip_skip{int(skip)}", r, TOL[dtype])
         assert r < TOL[dtype], f"{case} skip={skip}: rel-rms {r:.3e}"
     sattn = make_attn(case, cross=False).to(DEV, dtype)
     y = AttnProcessor2_0()(sattn, hs)
     r = rel_rms(y.float().cpu(), g["self"])
+    record_parity(f"processor.{case}.{str(dtype).split('.')[-1]}.self", r, TOL[dtype])
     assert r < TOL[dtype], f"{case} self: rel-rms {r:.3e}"
+
+
+# the shapes the benchmarked forward runs (cfg2: 1024^2, CFG batch 2; cfg4: batch 8, 16 Resampler tokens) against the
+# verbatim reference classes' outputs (sampled rows + whole-tensor row / column sums, oracle/gen_golden.py)
+TOL_CFG = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["cfg2_c1280_L1024_t4", "cfg2_c640_L4096_t4", "cfg4_c1280_L1024_t16_b8"])
+def test_processors_at_cfg_shapes_match_reference_golden(case, dtype):
+    from conftest import cmp_cfg_golden
+    from imagharmony_amd.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+    from oracle.gen_golden import ATTN_CFG_CASES
+    g = torch.load(os.path.join(GOLDEN, f"attn_{case}.pt"))
+    b, l, c, h, cd, nt, t, scale = ATTN_CFG_CASES[case]
+    hs, ehs = attn_inputs(case)
+    hs, ehs = hs.to(DEV, dtype), ehs.to(DEV, dtype)
+    attn = make_attn(case, cross=True).to(DEV, dtype)
+    tag = f"processor.{case}.{str(dtype).split('.')[-1]}"
+    for skip in (False, True):
+        p = det_fill(IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=skip), 17, prefix="proc.").to(DEV, dtype)
+        y = p(attn, hs, encoder_hidden_states=ehs)
+        assert y.shape == hs.shape and y.dtype == dtype
+        cmp_cfg_golden(y, g, case, f"ip_skip{int(skip)}", TOL_CFG[dtype], name=f"{tag}.ip_skip{int(skip)}")
+    sattn = make_attn(case, cross=False).to(DEV, dtype)
+    cmp_cfg_golden(AttnProcessor2_0()(sattn, hs), g, case, "self", TOL_CFG[dtype], name=f"{tag}.self")
 
 
 def test_processor_state_dict_and_surface():

@@ -278,3 +278,40 @@ def test_folded_layernorm_launches_only_get_variants_that_implement_it():
         assert (a.bm, a.bn) == table[:2]
     a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(1464, 160, 1), _args_only=True)[0]
     assert (a.bm, a.bn) == (1464, 160)                              # explicit: the C side is the one to refuse it
+
+
+def test_derived_weight_caches_follow_in_place_updates():
+    """packed / LayerNorm-folded weight copies are cached on the modules; their keys carry the in-place version counter of
+    every source tensor (weight, bias, norm.weight, norm.bias), so load_state_dict / weight.copy_ after a first forward
+    rebuild them -- the storage address alone does not change on an in-place update"""
+    from imagharmony_amd.attention_processor import _packed_qk, _cached, _vkey, fold_ln
+    from imagharmony_amd.ctx import Ctx
+    from imagharmony_amd.unet import Attention, Conv2d, GEGLU, Norm
+    ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
+    g = torch.Generator().manual_seed(0)
+    attn = Attention(64, 1)
+    norm, ge, conv = Norm(64, 1e-5), GEGLU(64, 128), Conv2d(64, 64, 3)
+    with torch.no_grad():
+        for p in list(attn.parameters()) + list(norm.parameters()) + list(ge.parameters()) + list(conv.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g))
+    qk0 = _packed_qk(attn, ctx).clone()
+    assert _packed_qk(attn, ctx).data_ptr() == _packed_qk(attn, ctx).data_ptr()          # cached while nothing changes
+    w0, b0, s0, c0 = [t.clone() for t in ge.packed_ln(ctx, norm)]
+    cw0 = conv.packed(ctx).clone()
+    key = lambda: (_vkey(attn.to_q.weight, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
+    f0 = [t.clone() for t in _cached(attn, "_imh_ln_q", key(), lambda: fold_ln(attn.to_q.weight, norm, ctx))]
+    with torch.no_grad():                 # in-place updates: same data_ptr, new version
+        attn.to_q.weight.mul_(2.0)
+        norm.bias.add_(1.0)
+        conv.weight.mul_(0.5)
+    assert not torch.equal(_packed_qk(attn, ctx), qk0)
+    w1, b1, s1, c1 = ge.packed_ln(ctx, norm)
+    assert torch.equal(w1, w0) and not torch.equal(c1, c0)                               # beta moved: c = W beta follows
+    assert torch.equal(conv.packed(ctx), (cw0.float() * 0.5).to(torch.bfloat16))
+    f1 = _cached(attn, "_imh_ln_q", key(), lambda: fold_ln(attn.to_q.weight, norm, ctx))
+    assert not torch.equal(f1[0], f0[0]) and not torch.equal(f1[2], f0[2])
+    sd = {k: v.clone() for k, v in attn.state_dict().items()}
+    qk1 = _packed_qk(attn, ctx).clone()
+    sd["to_k.weight"] = sd["to_k.weight"] + 1.0
+    attn.load_state_dict(sd)              # load_state_dict copies in place
+    assert not torch.equal(_packed_qk(attn, ctx), qk1)

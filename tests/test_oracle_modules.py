@@ -36,6 +36,23 @@ def test_attn_processors_match_reference_golden(case):
         assert rel_rms(y, g["self"]) < TOL
 
 
+@pytest.mark.parametrize("case", ["cfg2_c1280_L1024_t4", "cfg2_c640_L4096_t4"])
+def test_attn_processors_match_reference_golden_at_cfg_shapes(case):
+    """a1-a3 at the shapes of the benchmarked forward: the fixture holds sampled rows (fp16) and the row /
+    column sums of the verbatim reference classes' outputs"""
+    from conftest import cmp_cfg_golden
+    from oracle.gen_golden import ATTN_CFG_CASES
+    g = torch.load(os.path.join(GOLDEN, f"attn_{case}.pt"))
+    b, l, c, h, cd, nt, t, scale = ATTN_CFG_CASES[case]
+    hs, ehs = attn_inputs(case)
+    attn = make_attn(case, cross=True)
+    with torch.no_grad():
+        for skip in (False, True):
+            p = det_fill(om.IPAttnProcessor2_0(c, cd, scale=scale, num_tokens=t, skip=skip), 17, prefix="proc.")
+            cmp_cfg_golden(p(attn, hs, encoder_hidden_states=ehs), g, case, f"ip_skip{int(skip)}", 6e-4)   # fp16 storage of the rows
+        cmp_cfg_golden(om.AttnProcessor2_0()(make_attn(case, cross=False), hs), g, case, "self", 6e-4)
+
+
 def test_ip_scale_zero_equals_skip():
     case = "c128_t32"
     b, l, c, h, cd, nt, t, scale = ATTN_CASES[case]
