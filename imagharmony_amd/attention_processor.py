@@ -132,10 +132,12 @@ class AttnProcessor2_0(nn.Module):
         super().__init__()
 
     # -- recorded / fused path ------------------------------------------------------------
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None):
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, lk=None, ln=None, ln_stats=None, want_stats=False):
         """x: [B*L, C].  Returns to_out(attention(x)) (+ residual).
-        ln = norm module: x is the UN-normalised residual stream and that LayerNorm is folded into the projections
-        (statistics taken inside the GEMM); otherwise x is already layer-normed.
+        ln = norm module: x is the UN-normalised residual stream and that LayerNorm is folded into the projections;
+        ln_stats = (tensor, slots): the rows' statistics as left by the GEMM that wrote x (csrc/imh_lnstats.h), None -> taken
+        inside the projection GEMMs' K loops.  Without ln, x is already layer-normed.
+        want_stats: also return the row statistics of the result (the next LayerNorm's input) -> (out, stats).
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
         C_ = x.shape[1]
         H = attn.heads
@@ -150,15 +152,15 @@ class AttnProcessor2_0(nn.Module):
             fq, fv = _cached(attn, "_imh_ln_qkv", key, lambda: (
                 fold_ln(torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], 0), norm, ctx),
                 fold_ln(attn.to_v.weight, norm, ctx)))
-            g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps))
-            g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], norm.eps))
+            g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps, ln_stats))
+            g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], norm.eps, ln_stats))
         # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch
         qk, vt = ctx.gemm_dual(g1, g2, descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="self.to_out")
+                       descr="self.to_out", stats_out=want_stats)
         ctx.free(qk); ctx.free(vt); ctx.free(ao)
         return out
 
@@ -240,7 +242,9 @@ class IPAttnProcessor2_0(nn.Module):
             kv.k2, kv.vt2, kv.lk2, kv.lk2_pad = project_kv(ctx, ip, _w(self.to_k_ip, ctx), _w(self.to_v_ip, ctx))
         return kv
 
-    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None):
+    def emit(self, ctx, attn, x, B, L_, residual=None, kv=None, step=None, scale_tab=None, ln=None, ln_stats=None,
+             want_stats=False):
+        """ln / ln_stats / want_stats as in AttnProcessor2_0.emit"""
         C_ = x.shape[1]
         H = attn.heads
         if ln is None:
@@ -249,7 +253,7 @@ class IPAttnProcessor2_0(nn.Module):
             norm = ln
             key = (_vkey(attn.to_q.weight, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
             fq = _cached(attn, "_imh_ln_q", key, lambda: fold_ln(attn.to_q.weight, norm, ctx))
-            wq, lnq = fq[0], (fq[1], fq[2], norm.eps)
+            wq, lnq = fq[0], (fq[1], fq[2], norm.eps, ln_stats)
         ao = ctx.new(B * L_, C_)
         # to_q + text attention (+ image-prompt attention + text + scale * ip) in ONE launch (csrc/xattn.hip)
         if kv.k2 is not None:
@@ -261,7 +265,7 @@ class IPAttnProcessor2_0(nn.Module):
             ctx.cross_attention(x, wq, kv.k, kv.vt, ao, B, H, L_, kv.lk, kv.lk_pad, C_, B * kv.lk_pad, HEAD_DIM ** -0.5, ln=lnq,
                                 descr="cross.fused")
         out = ctx.gemm(ao, _w(attn.to_out[0], ctx), bias=_b(attn.to_out[0], ctx), residual=residual,
-                       descr="cross.to_out")
+                       descr="cross.to_out", stats_out=want_stats)
         ctx.free(ao)
         return out
 

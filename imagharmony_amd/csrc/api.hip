@@ -34,6 +34,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     GemmParams p;
     p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
     p.residual = a->residual; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.ln_eps = a->ln_eps;
+    p.ln_stats = a->ln_stats; p.ln_stats_out = a->ln_stats_out; p.ln_slots = a->ln_slots; p.ln_slots_out = a->ln_slots_out;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
@@ -48,10 +49,16 @@ static int do_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, hipStrea
     if (a->conv || b->conv || a->dtype != b->dtype) { set_error("gemm_dual: both problems must be plain GEMMs of one dtype"); return IMH_ERR_ARG; }
     int bm = a->bm, bn = a->bn;
     if (bm <= 0 || bn <= 0 || bm > 128) { bm = 128; bn = 64; }
-    for (const imh_gemm_args* g : {a, b})
+    for (const imh_gemm_args* g : {a, b}) {
         if ((g->flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!g->ln_s || !g->ln_c || !(g->ln_eps > 0.f))) {
             set_error("gemm_dual: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG;
         }
+        if (g->ln_stats_out) { set_error("gemm_dual: no statistics epilogue"); return IMH_ERR_ARG; }
+        if (g->ln_stats && (g->ln_slots <= 0 || g->K % g->ln_slots)) { set_error("gemm_dual: ln_slots=%d must divide K=%d", g->ln_slots, g->K); return IMH_ERR_ARG; }
+    }
+    if ((a->ln_stats == nullptr) != (b->ln_stats == nullptr) && ((a->flags | b->flags) & (IMH_GF_LN_ROW | IMH_GF_LN_COL))) {
+        set_error("gemm_dual: both problems take their LayerNorm statistics the same way"); return IMH_ERR_ARG;
+    }
     return gemm_dual_launch(to_gemm(a), to_gemm(b), a->dtype, bm, bn, s);
 }
 
@@ -60,6 +67,8 @@ static int do_gemm(const imh_gemm_args* a, hipStream_t s) {
     GemmParams p = to_gemm(a);
     if ((p.flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!p.ln_s || !p.ln_c || !(p.ln_eps > 0.f))) { set_error("gemm: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG; }
     if ((p.flags & IMH_GF_LN_ROW) && (p.flags & IMH_GF_LN_COL)) { set_error("gemm: IMH_GF_LN_ROW and IMH_GF_LN_COL are exclusive"); return IMH_ERR_ARG; }
+    if (!(p.flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL))) p.ln_stats = nullptr;
+    if (p.ln_stats && (p.ln_slots <= 0 || p.K % p.ln_slots)) { set_error("gemm: ln_slots=%d must divide K=%d", p.ln_slots, p.K); return IMH_ERR_ARG; }
     int bm = a->bm, bn = a->bn;
     if (bm <= 0 || bn <= 0 || p.splits <= 0) {
         int hb, hn, hs;
@@ -109,6 +118,8 @@ static int do_xattn(const imh_xattn_args* a, hipStream_t s) {
     p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     x.X = a->X; x.Wq = a->Wq; x.ln_s = a->ln_s; x.ln_c = a->ln_c; x.ln_eps = a->ln_eps;
+    x.ln_stats = a->ln_s ? a->ln_stats : nullptr; x.ln_slots = a->ln_slots;
+    if (x.ln_stats && (a->ln_slots <= 0 || a->C % a->ln_slots)) { set_error("cross_attention: ln_slots=%d must divide C=%d", a->ln_slots, a->C); return IMH_ERR_ARG; }
     x.C = a->C; x.ldx = a->ldx; x.ldw = a->ldw;
     return xattn_launch(x, a->dtype, s);
 }
@@ -210,6 +221,7 @@ int imh_abi_version(void) { return IMH_ABI_VERSION; }
 int imh_debug_set(int key, int value) {
     if (key == 0) { g_attn_force_nw = value; return IMH_OK; }
     if (key == 2) { g_xcd_mode = value; return IMH_OK; }
+    if (key == 3) { g_xattn_mode = value; return IMH_OK; }
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;
 }
@@ -223,6 +235,7 @@ int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
     return IMH_OK;
 }
 size_t imh_gemm_workspace_bytes(int M, int N, int splits) { return gemm_workspace_bytes(M, N, splits); }
+int imh_gemm_stats_slot_width(int bm, int bn) { return gemm_stats_slot_width(bm, bn); }
 
 int imh_attention(const imh_attn_args* a, void* stream) { return do_attn(a, (hipStream_t)stream); }
 

@@ -11,6 +11,7 @@
 //                 phi * std(eps_text) / std(eps_cfg) + (1 - phi), consumed by EW_CFG_STEP through `w`
 //   EW_SOFTMAX    row softmax of fp32 scores -> T probabilities (the VAE mid-block attention: one head of width
 //                 512 over 4096-16384 tokens, materialised as GEMM -> softmax -> GEMM; once per image)
+//   EW_ROW_STATS  (sum, M2) of token rows, the stand-alone LayerNorm-statistics producer (imh_lnstats.h)
 //   EW_CAST_F32   T -> fp32 copy (debug / host-side plumbing)
 //   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
 // Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
@@ -23,7 +24,7 @@
 namespace imh {
 
 enum : int { EW_TIMESTEP = 0, EW_SILU = 1, EW_CONCAT = 2, EW_CONV_IN = 3, EW_CFG_STEP = 4, EW_CAST_F32 = 5,
-             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8, EW_SOFTMAX = 9 };
+             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8, EW_SOFTMAX = 9, EW_ROW_STATS = 10 };
 
 // a: fp32 values [n_vals]; y: T [n_vals, dim]; cos first, then sin.
 template <typename T>
@@ -251,6 +252,34 @@ static inline int grid_for(long long work, int threads) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// EW_ROW_STATS: y[row] = (sum, M2 about the row mean) of a[row, 0:i0] (row stride i1 elements), ONE slot per row, in the
+// format of imh_lnstats.h -- the stand-alone producer of LayerNorm statistics for token rows whose writing GEMM variant
+// has no statistics epilogue (odd shapes / tiles).  One wave per row, two passes (the second hits L1).
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const EwParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.n) return;
+    const T* x = (const T*)p.a + row * p.i1;
+    const int C = p.i0;
+    float s = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const typename Vec<T>::v8 t = *(const typename Vec<T>::v8*)(x + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += to_f32(t[e]);
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float m2 = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const typename Vec<T>::v8 t = *(const typename Vec<T>::v8*)(x + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = to_f32(t[e]) - mean; m2 = __builtin_fmaf(d, d, m2); }
+    }
+    m2 = wave_sum(m2);
+    if (lane == 0) { float* y = (float*)p.y + row * 2; y[0] = s; y[1] = m2; }
+}
+
 template <typename T>
 static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
     switch (op) {
@@ -294,6 +323,10 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
             break;
         case EW_CAST_F32:
             hipLaunchKernelGGL((cast_f32_kernel<T>), dim3(grid_for(p.n, 256)), dim3(256), 0, stream, p);
+            break;
+        case EW_ROW_STATS:
+            if (p.n <= 0 || p.i0 <= 0 || (p.i0 & 7) || (p.i1 & 7) || !p.a) { set_error("row_stats: rows=%lld C=%d ld=%d (C and ld must be multiples of 8)", p.n, p.i0, p.i1); return IMH_ERR_SHAPE; }
+            hipLaunchKernelGGL((row_stats_kernel<T>), dim3((unsigned)((p.n + 3) / 4)), dim3(256), 0, stream, p);
             break;
         case EW_STEP_SET:
             hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(64), 0, stream, (int*)p.y, p.i0, p.i1);

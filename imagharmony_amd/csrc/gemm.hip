@@ -28,10 +28,12 @@ int g_xcd_mode = 0;
 
 
 // LN: 0 = none; 1 = folded LayerNorm with the token rows as the X operand (GF_LN_ROW); 2 = token rows as the W operand
-// (GF_LN_COL, the swapped-operand V^T projection).  For LN != 0 the row statistics (sum, sum of squares over K) are
+// (GF_LN_COL, the swapped-operand V^T projection).  For LN = 1 / 2 the row statistics (sum, sum of squares over K) are
 // accumulated INSIDE the K loop from the operand fragments the MFMAs consume anyway (8 v_dot2c per fragment, issued
 // under the MFMAs), so BasicTransformerBlock.norm1/2/3 cost no launch, no pass over the residual stream and no
-// statistics buffer.  Needs splits == 1 (the whole K range in one workgroup).
+// statistics buffer.  LN = 3 / 4: the same two forms with the statistics PRECOMPUTED by the GEMM that wrote the token rows
+// (p.ln_stats, imh_lnstats.h): the tile's token rows are merged by one thread each while the first K tile is in flight and
+// parked in LDS behind the two stages; nothing statistical remains in the K loop.  Needs splits == 1.
 template <typename T, int BM, int BN, bool CONV, int LN>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, const int z) {
     constexpr int FM = BM / 32;   // 16-row token fragments per wave
@@ -148,13 +150,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NS = LN == 1 ? FM : (LN == 2 ? FN : 1);
+    constexpr int NS = (LN == 1 || LN == 3) ? FM : (LN == 2 ? FN : 1);
     float st_s[NS], st_q[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    f32x2s* const lnst = (f32x2s*)(smem + 2 * STAGE);      // LN = 3 / 4: (mean, rstd) of the tile's token rows
 
     if (kt0 < kt1) {
         stage(0, kt0);
+        if constexpr (LN == 3 || LN == 4) {                // beside the first tile's flight (the wait below covers both)
+            constexpr int NTOK = LN == 3 ? BM : BN;
+            if (tid < NTOK) {
+                const int tok = (LN == 3 ? m0 : n0) + tid;
+                f32x2s mr = {0.f, 1.f};
+                if (tok < (LN == 3 ? p.M : p.N)) mr = merge_row_stats(p.ln_stats, tok, p.ln_slots, p.K, p.ln_eps);
+                lnst[tid] = mr;
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA landed (also implied by the fence below)
         __syncthreads();
         int cur = 0;
@@ -202,7 +214,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     float lnpre[8 * FN];
     const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
     LnArgs<4 * FN> ln;
-    if constexpr (LN != 0) {
+    if constexpr (LN == 3) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const f32x2s mr = lnst[wm * (BM / 2) + i * 16 + (lane & 15)];
+            st_s[i] = mr[0]; st_q[i] = mr[1];
+        }
+    }
+    if constexpr (LN == 4) {
+#pragma unroll
+        for (int q = 0; q < 4 * FN; ++q) {
+            const f32x2s mr = lnst[wn * (BN / 2) + (lane >> 4) * 4 * FN + q];
+            ln.cm[q] = mr[0]; ln.cr[q] = mr[1];
+        }
+    }
+    if constexpr (LN == 1 || LN == 2) {
         // every lane of a 16-lane row holds the partial sums of fragment row (lane & 15) over ITS 8-element k-slices:
         // combine the four lane groups (permlane swaps, no LDS), then mean / rstd per fragment row
         const float invk = 1.0f / (float)p.K;
@@ -262,8 +288,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }     // fragment i's row (lane & 15) IS output row m
-            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr);
+            if constexpr (LN == 1 || LN == 3) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }     // fragment i's row (lane & 15) IS output row m
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr, nullptr, lane);
         }
     }
     if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, gridDim.x, tid, 256);
@@ -277,11 +303,12 @@ IMH_KERNEL __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // Two independent problems in ONE launch (e.g. self-attention's [Q|K] = x [Wq;Wk]^T and V^T = Wv x^T, which
 // share x): workgroups [0, grid_a) run problem a, the rest problem b.  Halves the launch count of the pair and
 // lets the two sub-chip-sized grids fill the machine together.
-// LNP: false = plain problems; true = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both).
-template <typename T, int BM, int BN, bool LNP>
+// LNP: 0 = plain problems; 1 = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both, statistics
+// taken in the K loops); 2 = the same with precomputed statistics (p.ln_stats).
+template <typename T, int BM, int BN, int LNP>
 IMH_KERNEL __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
-    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP ? 1 : 0>(a, blockIdx.x, 0);
-    else gemm_body<T, BM, BN, false, LNP ? 2 : 0>(b, blockIdx.x - grid_a, 0);
+    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP == 0 ? 0 : (LNP == 1 ? 1 : 3)>(a, blockIdx.x, 0);
+    else gemm_body<T, BM, BN, false, LNP == 0 ? 0 : (LNP == 1 ? 2 : 4)>(b, blockIdx.x - grid_a, 0);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
@@ -318,9 +345,18 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
-    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
+    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES + (p.ln_stats ? (BM > BN ? BM : BN) * 8 : 0);
     dim3 grid(tiles, p.splits, 1);
-    if (!CONV && (p.flags & GF_LN_ROW)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 1>), grid, dim3(256), smem, stream, q);
+    if (!CONV && (p.flags & GF_LN_ROW) && p.ln_stats) {
+        static DynLdsOnce once;
+        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 3>, (int)smem);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 3>), grid, dim3(256), smem, stream, q);
+    } else if (!CONV && (p.flags & GF_LN_COL) && p.ln_stats) {
+        static DynLdsOnce once;
+        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 4>, (int)smem);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 4>), grid, dim3(256), smem, stream, q);
+    }
+    else if (!CONV && (p.flags & GF_LN_ROW)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 1>), grid, dim3(256), smem, stream, q);
     else if (!CONV && (p.flags & GF_LN_COL)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 2>), grid, dim3(256), smem, stream, q);
     else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 0>), grid, dim3(256), smem, stream, q);
     return check_launch("gemm_kernel");
@@ -372,9 +408,14 @@ static int launch_dual_tile(const GemmParams& a, const GemmParams& b, hipStream_
     int ga, gb;
     xcd_partition(qa, BM, BN, &ga);
     xcd_partition(qb, BM, BN, &gb);
-    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES;
-    if (a.flags & GF_LN_ROW) hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, true>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
-    else hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, false>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES + (a.ln_stats ? (BM > BN ? BM : BN) * 8 : 0);
+    if ((a.flags & GF_LN_ROW) && a.ln_stats) {
+        static DynLdsOnce once;
+        once.ensure((const void*)gemm_dual_kernel<T, BM, BN, 2>, (int)smem);
+        hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 2>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    }
+    else if (a.flags & GF_LN_ROW) hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 1>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    else hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 0>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
     return check_launch("gemm_dual_kernel");
 }
 
@@ -426,6 +467,14 @@ void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
     *bm = cbm; *bn = cbn; *splits = s;
 }
 
+// statistics epilogue (imh_lnstats.h): a wave's four 16-lane groups own one slot of consecutive columns
+int gemm_stats_slot_width(int bm, int bn) {
+    if ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return bn / 2;          // plain tiles: 2 x 2 waves
+    if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256) && bn == 160) return 80;   // wave-specialised, CN = 2
+    if (bm == 24128 && bn == 128) return 64;
+    return 0;
+}
+
 size_t gemm_workspace_bytes(int M, int N, int splits) {
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
@@ -439,8 +488,20 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256) && (p.flags & GF_LN_ROW))) || conv)) {
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || (bm == 1464 && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
         set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
+        return IMH_ERR_ARG;
+    }
+    if (p.ln_stats_out) {
+        const int w = gemm_stats_slot_width(bm, bn);
+        if (w == 0 || p.N % w || p.ln_slots_out != p.N / w || conv || p.splits > 1 || (p.flags & (GF_GEGLU | GF_VT_PERM | GF_OUT_F32))) {
+            set_error("gemm: ln_stats_out needs a variant with a statistics epilogue (slot width %d for %dx%d), N %% width == 0, "
+                      "ln_slots_out == N / width, a plain output (N=%d slots=%d flags=%d splits=%d conv=%d)", w, bm, bn, p.N, p.ln_slots_out, p.flags, p.splits, conv);
+            return IMH_ERR_ARG;
+        }
+    }
+    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256)) {
+        set_error("gemm: precomputed LayerNorm statistics need a plain tile or a wave-specialised variant (bm=%d)", bm);
         return IMH_ERR_ARG;
     }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);

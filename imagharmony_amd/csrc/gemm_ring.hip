@@ -10,6 +10,7 @@
 #include "imh_common.h"
 #include "imh_kernels.h"
 #include "imh_gemm_epilogue.h"
+#include "imh_lnstats.h"
 #include <type_traits>
 
 namespace imh {
@@ -406,7 +407,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
 #endif
-// CM x CN consumer waves over the tile; LN = 1: folded LayerNorm, row form.  The producer group then splits once more:
+// CM x CN consumer waves over the tile; LN = 2: folded LayerNorm, row form, statistics PRECOMPUTED by the GEMM that wrote the
+// token rows (imh_lnstats.h): before their first hand-over the consumer threads merge the slot partials of the tile's BM rows
+// (one thread per row, loads in flight beside the producers' ring prologue) into an LDS area behind the ring -- no
+// statistics work inside the K loop, all NP producers load.  LN = 1: the same with the statistics taken in the loop (no
+// producer kernel supplies them).  The producer group then splits once more:
 // two LOADER waves run the LDS-DMA ring and the other NP - 2 are STATISTICS waves -- thread t owns token rows t, t + TS, ...
 // of the tile and adds up their 128 bytes of every landed K tile straight from LDS (v_dot2c sums), in parallel with the
 // loaders' issue and with every VALU instruction kept out of the waves that feed the MFMA pipe; mean / rstd reach the
@@ -416,8 +421,9 @@ template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, 
 __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
     constexpr int NC = CM * CN;
     constexpr int TM = BM / CM, TN = BN / CN;
-    static_assert(LN == 0 || (!CONV && NP >= 3), "LN: two loader waves + NP - 2 statistics waves");
-    constexpr int NL = LN == 1 ? 2 : NP;           // loader waves; with LN the other producers only sum rows
+    static_assert(LN != 1 || (!CONV && NP >= 3), "LN = 1: two loader waves + NP - 2 statistics waves");
+    static_assert(LN != 2 || !CONV, "folded LayerNorm is a Linear-layer form");
+    constexpr int NL = LN == 1 ? 2 : NP;           // loader waves; with in-loop LN the other producers only sum rows
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
     constexpr int NI = (BM + BN) / 8;              // ... and in total
@@ -627,6 +633,16 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
         }
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
     };
+    if constexpr (LN == 2) {                       // (mean, rstd) of the tile's rows -> LDS area behind the ring
+        const int t = wave * 64 + lane;
+        if (t < BM) {
+            const int m = m0 + t;
+            f32x2s mr = {0.f, 1.f};
+            if (m < p.M) mr = merge_row_stats(p.ln_stats, m, p.ln_slots, p.K, p.ln_eps);
+            *(f32x2s*)(smem + S * STAGE + t * 8) = mr;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                  // tile 0 has landed
     asm volatile("" ::: "memory");
     int slot = 0;
@@ -657,8 +673,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
     if (pre.ok && p.bias) ldv<T, 4 * FN>((const T*)p.bias + nb, pre.bias);
     LnArgs<4 * FN> ln;
     float st_s[FM], st_q[FM];
-    if constexpr (LN == 1) {                       // mean / rstd of the tile's rows, published by the producers (see above)
-        const float* ex = (const float*)(smem + ((nt + S - 2) % S) * STAGE);
+    if constexpr (LN != 0) {                       // mean / rstd of the tile's rows: published by the statistics waves (LN = 1, see
+        // above) or merged from the producer kernel's partials before the loop (LN = 2)
+        const float* ex = (const float*)(smem + (LN == 2 ? S : ((nt + S - 2) % S)) * STAGE);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int r = wm * TM + i * 16 + (lane & 15);
@@ -666,7 +683,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             st_q[i] = ex[r * 2 + 1];
         }
     }
-    if constexpr (LN == 1) {
+    if constexpr (LN != 0) {
         // the transformer blocks' launches (ff.net.0: LN + bias + GEGLU; to_q / to_k: LN only) take a lean epilogue: whole
         // 4*FN-column run in range, vector-aligned output, no row-add / residual / activation -- operands fetched once
         // above, then per row the LN formula, the GEGLU product and ONE store
@@ -731,6 +748,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bs[j * 4 + r] + rr[i][j * 4 + r];
                 stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+                if (p.ln_stats_out) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
             }
             return;
         }
@@ -754,8 +772,8 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
-            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre);
+            if constexpr (LN != 0) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane);
         }
     }
 }
@@ -765,7 +783,7 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
-    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES;
+    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 2 ? BM * 8 : 0);
     auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
@@ -775,6 +793,9 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV>
 static int launch_ws(const GemmParams& p, hipStream_t stream) {
+    if constexpr (!CONV) {
+        if ((p.flags & GF_LN_ROW) && p.ln_stats) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 2>(p, stream);
+    }
     if constexpr (!CONV && NP >= 3) {
         if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1>(p, stream);
     }

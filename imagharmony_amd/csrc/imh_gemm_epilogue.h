@@ -3,6 +3,7 @@
 #pragma once
 #include "imh_common.h"
 #include "imh_kernels.h"
+#include "imh_lnstats.h"
 
 namespace imh {
 
@@ -158,7 +159,8 @@ __device__ __forceinline__ void epilogue_preload(const GemmParams& p, int m, int
 template <typename T, int FN>
 __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&v)[4 * FN], int m, int nb,
                                                    const float (&lnpre)[8 * FN], const bool have_pre,
-                                                   const LnArgs<4 * FN>* ln = nullptr, const EpiPre<4 * FN>* pre = nullptr) {
+                                                   const LnArgs<4 * FN>* ln = nullptr, const EpiPre<4 * FN>* pre = nullptr,
+                                                   const int lane = -1) {
     constexpr int NV = 4 * FN;
     constexpr int NH = NV / 2;
     const T* bias = (const T*)p.bias;
@@ -265,6 +267,9 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
         return;
     }
     T* y = (T*)p.Y + (size_t)m * p.ldy + nb;
+    // statistics hand-over to the LayerNorm-folding consumer of Y (the launcher only sets ln_stats_out for variants that pass
+    // their lane here, for full-width slots: N % (4 * NV) == 0, and for plain T outputs)
+    if (p.ln_stats_out && lane >= 0) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
     if (fast) stv<T, NV>(y, v);
     else {
 #pragma unroll

@@ -18,6 +18,12 @@ struct GemmParams {
     const float* ln_s;     // sum_k gamma_k W[.,k]   (row form: per n; col form: per m)
     const float* ln_c;     // sum_k beta_k  W[.,k]   (same indexing as ln_s)
     float ln_eps;
+    // row statistics hand-over (imh_lnstats.h): ln_stats = precomputed (sum, M2) slot partials of the token rows [tokens][ln_slots][2]
+    // (null -> the kernel takes the statistics inside its K loop); ln_stats_out = partials of THIS launch's output rows
+    // [M][ln_slots_out][2], written by the epilogue (null -> none)
+    const float* ln_stats;
+    float* ln_stats_out;
+    int ln_slots, ln_slots_out;
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;
@@ -33,6 +39,7 @@ struct GemmParams {
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 size_t gemm_workspace_bytes(int M, int N, int splits);
+int gemm_stats_slot_width(int bm, int bn);     // channels per ln_stats_out slot of a tile variant, 0 = no statistics epilogue
 int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
 int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream);
 
@@ -65,10 +72,13 @@ struct XAttnParams {
     const float* ln_s;    // [H*64] sum_k gamma_k Wq[d, k]  or null
     const float* ln_c;    // [H*64] sum_k beta_k  Wq[d, k]
     float ln_eps;
+    const float* ln_stats;   // precomputed row statistics of X (imh_lnstats.h) or null
+    int ln_slots;
     int C, ldx, ldw;
 };
 int xattn_launch(const XAttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
+extern int g_xattn_mode;
 extern int g_xcd_mode;
 
 struct SmallAttnParams {

@@ -1,0 +1,86 @@
+// Row statistics of the transformer blocks' residual stream, handed from the GEMM that WRITES a LayerNorm input
+// (to_out + residual, ff.out + residual, proj_in) to the kernels that consume it with the LayerNorm folded in
+// (ff.net.0, [Q|K] + V^T, the fused cross-attention's to_q): diffusers BasicTransformerBlock.norm1/2/3
+//  without a pass over the tensor and without statistics work inside the consumers' K loops.
+//
+// Format: stats[token][slot] = (sum, M2) as two floats, one slot per run of SW consecutive channels (SW = the width
+// a producing wave owns: 80 for the wave-specialised 160-column tiles, BN / 2 for the plain tiles), M2 = sum of
+// squared deviations from the SLOT mean, both taken from the values as rounded to the output dtype (what the consumer
+// will read).  Slots are merged with Chan's formula, so the variance never comes from E[x^2] - mean^2 and a large
+// common offset of a row costs no precision (torch's LayerNorm, which the reference runs, is Welford-based too).
+#pragma once
+#include "imh_common.h"
+
+namespace imh {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2s;
+
+// Producer side.  The four 16-lane groups of a wave hold four consecutive NV-column runs of the same output rows
+// (lane l, l ^ 16, l ^ 32, l ^ 48 share row l & 15): per lane a two-pass (sum, M2) over its NV values, two equal-count
+// Chan merges through v_permlane16_swap / v_permlane32_swap, and lanes 0-15 store the slot's pair.
+// nb = first column of the lane's run; the slot is nb / (4 * NV).  Every lane of the wave must call this (the rows of
+// one 16-lane group are either all valid or all skipped by the caller's row guard: same row, same m).
+template <typename T, int NV>
+__device__ __forceinline__ void emit_row_stats(float* stats, const int slots, const int m, const int nb, const float* v,
+                                               const int lane) {
+    float r[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { r[q] = to_f32(from_f32<T>(v[q])); s += r[q]; }
+    const float mean = s * (1.0f / NV);
+    float m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { const float d = r[q] - mean; m2 = __builtin_fmaf(d, d, m2); }
+    {   // rows of 16 lanes: {0,1} and {2,3} (v_permlane16_swap with itself leaves {r0,r0,r2,r2} / {r1,r1,r3,r3})
+        auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m2), __builtin_bit_cast(unsigned, m2), false, false);
+        const float s0 = __builtin_bit_cast(float, (unsigned)a[0]), s1 = __builtin_bit_cast(float, (unsigned)a[1]);
+        const float d = s0 - s1;
+        m2 = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]) + d * d * (0.5f / NV);
+        s = s0 + s1;
+    }
+    {   // halves of the wave
+        auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2), __builtin_bit_cast(unsigned, m2), false, false);
+        const float s0 = __builtin_bit_cast(float, (unsigned)a[0]), s1 = __builtin_bit_cast(float, (unsigned)a[1]);
+        const float d = s0 - s1;
+        m2 = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]) + d * d * (0.25f / NV);
+        s = s0 + s1;
+    }
+    if (lane < 16) {
+        f32x2s o = {s, m2};
+        *(f32x2s*)(stats + ((size_t)m * slots + nb / (4 * NV)) * 2) = o;
+    }
+}
+
+// Consumer side: (mean, rstd) of one token row from its `slots` partials (equal counts K / slots each).  The loads of a
+// batch are unconditional (index clamped; a clamped duplicate enters the merge with weight 0): a guarded load would make
+// hipcc branch around and wait for every element.  One thread per row.
+__device__ __forceinline__ f32x2s merge_row_stats(const float* stats, const int row, const int slots, const int K,
+                                                  const float eps) {
+    const f32x2s* st = (const f32x2s*)(stats + (size_t)row * slots * 2);
+    const float ni = (float)K / (float)slots;
+    const float inv_ni = 1.0f / ni;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i0 = 0; i0 < slots; i0 += 16) {
+        f32x2s t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = st[min(i0 + j, slots - 1)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float w = (i0 + j < slots) ? ni : 0.f;
+            const float nn = n + w;
+            const float f = w * __builtin_amdgcn_rcpf(fmaxf(nn, 1.0f));     // share of the new partial
+            const float d = t[j][0] * inv_ni - mean;
+            mean = __builtin_fmaf(d, f, mean);
+            m2 += (w > 0.f ? t[j][1] : 0.f) + d * d * n * f;
+            n = nn;
+        }
+    }
+    f32x2s o;
+    o[0] = mean;
+    o[1] = rsqrtf(m2 / (float)K + eps);
+    return o;
+}
+
+}  // namespace imh

@@ -24,12 +24,17 @@
 //              pass, text + scale * ip formed in registers, one coalesced store.
 // Roofline: the prologue is a GEMM (MFMA-bound, 2*B*L*C^2 FLOP per call); the key loop over 77 + T keys is short.
 #include "imh_attn_core.h"
+#include "imh_lnstats.h"
 
 namespace imh {
 
+int g_xattn_mode = 0;   // imh_debug_set key 3: 0 auto (two heads per workgroup when H is even), 1 one head per workgroup (round-2 kernel),
+                        // 2 two heads, eight do-everything waves, 3 two heads + two producer waves, 4 two heads + four producer waves
+
+
 constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
 
-template <typename T, int NPASS, bool LNQ>
+template <typename T, int NPASS, int LNQ>
 __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XAttnParams xp) {
     constexpr int NW = 4;
     typedef typename Vec<T>::v8 v8;
@@ -93,6 +98,10 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 
     const int nkt = xp.C / 64;
     stage(0, 0);
+    if constexpr (LNQ == 2) {      // precomputed row statistics (imh_lnstats.h): lane (q, hi) merges its query row's slots
+        const f32x2s mr = merge_row_stats(xp.ln_stats, b * p.Lq + min(q0 + wave * 32 + (lane & 31), p.Lq - 1), xp.ln_slots, xp.C, xp.ln_eps);
+        st_s = mr[0]; st_q = mr[1];
+    }
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile kt has landed
         __builtin_amdgcn_s_barrier();                         // ... everyone's has; tile kt-1 is fully consumed
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
-        if constexpr (LNQ) {
+        if constexpr (LNQ == 1) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
         }
@@ -125,11 +134,12 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     v8 qf[4];
     {
         float mean = 0.f, rstd = 1.f;
-        if constexpr (LNQ) {
+        if constexpr (LNQ == 1) {
             const float invc = 1.0f / (float)xp.C;
             mean = xor32_sum(st_s) * invc;                     // the row's other k-slices live in lane ^ 32
             rstd = rsqrtf(fmaxf(xor32_sum(st_q) * invc - mean * mean, 0.f) + xp.ln_eps);
         }
+        if constexpr (LNQ == 2) { mean = st_s; rstd = st_q; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = qa[dt][rg * 4 + e];
-                if constexpr (LNQ) {
+                if constexpr (LNQ != 0) {
                     const int d = h * 64 + att_o_dim(dt, rg * 4, hi);          // 4 consecutive head dims
                     const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
 #pragma unroll
@@ -152,6 +162,224 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     attn_core<T, NW, NPASS>(p, smem, qf, b, h, wave, lane, item, fin);
     attn_store<T, NW>(p, smem, fin, b, h, q0, wave, lane);
     tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two heads per workgroup.  One workgroup = (batch, head PAIR, 128 queries) = 8 consumer waves (head g = wave >> 2, query
+// group wave & 3) [+ NP producer waves].  Against the one-head kernel above: a 128-query block of X is fetched by H / 2
+// items instead of H (16 KB of tokens + 16 KB of weights per 2.1 MFLOP K tile instead of 16 + 8 per 1.05), the K loop is an
+// S-stage LDS-DMA ring with counted vmcnt (never drained; the one-head kernel waits vmcnt(0) + barrier every K tile), and
+// with NP > 0 the LDS-DMA issue lives in producer waves that do nothing else (gemm_ws_kernel's structure: ONE s_barrier per
+// K tile carries "tile i + 1 has landed" and "tile i has been read").  The producers exit after the projection; the two
+// 4-wave groups then run the shared key loop (imh_attn_core.h) side by side, each on its own half of the LDS
+// (s_barrier waits on surviving waves only).
+constexpr int XQ2_STAGE = 128 * 128 + 128 * 128;   // X tile (128 token rows) + Wq tile (2 heads x 64 dims), 128 B per row
+
+template <typename T, int NPASS, int LNQ, int NP, int S>
+__global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnParams xp) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int NI = 32;                              // LDS-DMA wave instructions per K tile (8 rows x 128 B each)
+    constexpr int NISS = NP > 0 ? NP : 8;               // waves that issue them
+    constexpr int LP = NI / NISS;
+    constexpr int GROUP_BYTES = ATT_STAGES * 2 * ATT_TILE_BYTES;      // one head group's K / V^T ring (+ Q / O staging rows)
+    static_assert(S * XQ2_STAGE >= 2 * GROUP_BYTES, "the projection ring covers both key-loop rings");
+    static_assert((S - 2) * LP <= 63 && NI % NISS == 0, "vmcnt range / even split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AttnParams& p = xp.a;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int gx = (p.Lq + 127) / 128;
+    const int HP = p.H >> 1;
+    const int items = gx * HP * p.B;
+    const int per = (items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    const int hb = item / gx, qblk = item - hb * gx;
+    const int b = hb / HP, h0 = (hb - b * HP) * 2;
+    const int q0 = qblk * 128;
+    const int nkt = xp.C / 64;
+
+    // staging map: instruction rb (0..31) fills tile rows rb*8 .. rb*8+7; rows 0..127 = tokens, 128..255 = weight rows
+    auto src_of = [&](int rb) -> const unsigned char* {
+        const int r = rb * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swz_x(r & 127);
+        if (rb < 16) return (const unsigned char*)((const T*)xp.X + ((size_t)b * p.Lq + min(q0 + r, p.Lq - 1)) * xp.ldx + ch * 8);
+        return (const unsigned char*)((const T*)xp.Wq + ((size_t)h0 * 64 + (r - 128)) * xp.ldw + ch * 8);
+    };
+
+    if (NP > 0 && wave >= 8) {
+        // ------------------------------------------------------------------ producer
+        const int pw = wave - 8;
+        const unsigned char* src[LP];
+#pragma unroll
+        for (int k = 0; k < LP; ++k) src[k] = src_of(k * NISS + pw);
+        auto issue = [&](int slot, int kt) {
+#pragma unroll
+            for (int k = 0; k < LP; ++k) glds16(src[k] + (size_t)kt * 128, smem + slot * XQ2_STAGE + (k * NISS + pw) * 1024);
+        };
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nkt) issue(s, s);
+        if (S - 1 <= nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // tile 0 has landed
+        int slot = S - 1;
+        for (int i = 0; i < nkt; ++i) {
+            if (i + S - 1 < nkt) issue(slot, i + S - 1);   // into the slot tile i - 1 was read from
+            if (i + S <= nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // tile i + 1 has landed, tile i has been read
+            if (++slot == S) slot = 0;
+        }
+        tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid - 512, 64 * NP);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int g = wave >> 2, qg = wave & 3;
+    const int h = h0 + g;
+    int xoff[4], woff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        xoff[ks] = xq_x_off(qg, lane, ks);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) woff[dt][ks] = 128 * 128 + xq_w_off(g * 2 + dt, lane, ks);
+    }
+    f32x16 qa[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qa[dt][r] = 0.f;
+    float st_s = 0.f, st_q = 0.f;
+
+    const unsigned char* src[NP > 0 ? 1 : LP];
+    if constexpr (NP == 0) {
+#pragma unroll
+        for (int k = 0; k < LP; ++k) src[k] = src_of(k * 8 + wave);
+    }
+    auto issue = [&](int slot, int kt) {
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int k = 0; k < LP; ++k) glds16(src[k] + (size_t)kt * 128, smem + slot * XQ2_STAGE + (k * 8 + wave) * 1024);
+        }
+    };
+    if constexpr (NP == 0) {
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nkt) issue(s, s);
+    }
+    if constexpr (LNQ == 2) {      // precomputed row statistics: lane (q, hi) merges its query row's slots (loads in flight
+        // beside the ring prologue)
+        const f32x2s mr = merge_row_stats(xp.ln_stats, b * p.Lq + min(q0 + qg * 32 + (lane & 31), p.Lq - 1), xp.ln_slots, xp.C, xp.ln_eps);
+        st_s = mr[0]; st_q = mr[1];
+    }
+    if constexpr (NP > 0) {
+        __builtin_amdgcn_s_barrier();                      // tile 0 has landed
+        asm volatile("" ::: "memory");
+    }
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if constexpr (NP == 0) {
+            if (kt + S - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // everyone's part of tile kt is in LDS; tile kt - 1 fully consumed
+            asm volatile("" ::: "memory");
+            if (kt + S - 1 < nkt) {
+                int ns = slot + S - 1;
+                if (ns >= S) ns -= S;
+                issue(ns, kt + S - 1);
+            }
+        }
+        const unsigned char* sb = smem + slot * XQ2_STAGE;
+        v8 xf[4], wf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            xf[ks] = *(const v8*)(sb + xoff[ks]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) wf[dt][ks] = *(const v8*)(sb + woff[dt][ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
+        if constexpr (LNQ == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
+        }
+        if constexpr (NP > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tile kt has been read: its slot may be refilled
+            __builtin_amdgcn_s_barrier();                            // ... and tile kt + 1 has landed
+        }
+        asm volatile("" ::: "memory");
+        if (++slot == S) slot = 0;
+    }
+    if constexpr (NP == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // every wave is done with the projection stages: the K / V^T rings may reuse them
+    }
+
+    v8 qf[4];
+    {
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (LNQ == 1) {
+            const float invc = 1.0f / (float)xp.C;
+            mean = xor32_sum(st_s) * invc;
+            rstd = rsqrtf(fmaxf(xor32_sum(st_q) * invc - mean * mean, 0.f) + xp.ln_eps);
+        }
+        if constexpr (LNQ == 2) { mean = st_s; rstd = st_q; }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = qa[dt][rg * 4 + e];
+                if constexpr (LNQ != 0) {
+                    const int d = h * 64 + att_o_dim(dt, rg * 4, hi);
+                    const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fma_nopk(rstd, fma_nopk(-mean, s4[e], v[e]), c4[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[xq_sd(dt, rg * 4 + e)][xq_slot(rg * 4 + e)] = from_f32<T>(v[e]);
+            }
+    }
+
+    unsigned char* gs = smem + g * GROUP_BYTES;
+    f32x16 fin[2];
+    attn_core<T, 4, NPASS>(p, gs, qf, b, h, qg, lane, item, fin);
+    attn_store<T, 4>(p, gs, fin, b, h, q0, qg, lane);
+    if (NP == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 512);
+}
+
+template <typename T, int NPASS, int LNQ, int NP, int S>
+static void launch_xattn2(const XAttnParams& xp, hipStream_t stream) {
+    const AttnParams& p = xp.a;
+    const int items = ((p.Lq + 127) / 128) * (p.H / 2) * p.B;
+    dim3 grid(8 * ((items + 7) / 8));
+    const int lds = S * XQ2_STAGE;
+    auto kern = xattn2_kernel<T, NPASS, LNQ, NP, S>;
+    static DynLdsOnce once;
+    once.ensure((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + NP)), lds, stream, xp);
+}
+
+template <typename T, int NP, int S>
+static void launch_xattn2_np(const XAttnParams& xp, hipStream_t stream) {
+    const int lnq = !xp.ln_s ? 0 : (xp.ln_stats ? 2 : 1);
+    if (xp.a.K2) {
+        if (lnq == 0) launch_xattn2<T, 2, 0, NP, S>(xp, stream);
+        else if (lnq == 1) launch_xattn2<T, 2, 1, NP, S>(xp, stream);
+        else launch_xattn2<T, 2, 2, NP, S>(xp, stream);
+    } else {
+        if (lnq == 0) launch_xattn2<T, 1, 0, NP, S>(xp, stream);
+        else if (lnq == 1) launch_xattn2<T, 1, 1, NP, S>(xp, stream);
+        else launch_xattn2<T, 1, 2, NP, S>(xp, stream);
+    }
 }
 
 int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
@@ -171,17 +399,31 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     }
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("cross_attention: empty problem"); return IMH_ERR_SHAPE; }
     if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("cross_attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
-    const int items = ((p.Lq + 127) / 128) * p.H * p.B;
-    dim3 grid(8 * ((items + 7) / 8));
-    const bool ln = xp.ln_s != nullptr;
-#define IMH_XA(TT) do { \
-        if (p.K2) { if (ln) hipLaunchKernelGGL((xattn_kernel<TT, 2, true>), grid, dim3(256), 0, stream, xp); \
-                    else hipLaunchKernelGGL((xattn_kernel<TT, 2, false>), grid, dim3(256), 0, stream, xp); } \
-        else { if (ln) hipLaunchKernelGGL((xattn_kernel<TT, 1, true>), grid, dim3(256), 0, stream, xp); \
-               else hipLaunchKernelGGL((xattn_kernel<TT, 1, false>), grid, dim3(256), 0, stream, xp); } } while (0)
-    if (dtype == IMH_DT_BF16) IMH_XA(bf16_t);
-    else IMH_XA(f16_t);
+    int mode = g_xattn_mode;
+    if (mode == 0) mode = 3;
+    if ((p.H & 1) || mode == 1) {
+        const int items = ((p.Lq + 127) / 128) * p.H * p.B;
+        dim3 grid(8 * ((items + 7) / 8));
+        const int lnq = !xp.ln_s ? 0 : (xp.ln_stats ? 2 : 1);
+#define IMH_XA1(TT, NPV) do { \
+            if (lnq == 0) hipLaunchKernelGGL((xattn_kernel<TT, NPV, 0>), grid, dim3(256), 0, stream, xp); \
+            else if (lnq == 1) hipLaunchKernelGGL((xattn_kernel<TT, NPV, 1>), grid, dim3(256), 0, stream, xp); \
+            else hipLaunchKernelGGL((xattn_kernel<TT, NPV, 2>), grid, dim3(256), 0, stream, xp); } while (0)
+#define IMH_XA(TT) do { if (p.K2) IMH_XA1(TT, 2); else IMH_XA1(TT, 1); } while (0)
+        if (dtype == IMH_DT_BF16) IMH_XA(bf16_t);
+        else IMH_XA(f16_t);
 #undef IMH_XA
+#undef IMH_XA1
+    } else if (mode == 2) {
+        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 0, 4>(xp, stream);
+        else launch_xattn2_np<f16_t, 0, 4>(xp, stream);
+    } else if (mode == 4) {
+        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 4, 4>(xp, stream);
+        else launch_xattn2_np<f16_t, 4, 4>(xp, stream);
+    } else {
+        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 2, 4>(xp, stream);
+        else launch_xattn2_np<f16_t, 2, 4>(xp, stream);
+    }
     return check_launch("xattn_kernel");
 }
 

@@ -153,20 +153,54 @@ class Ctx:
             raise L.ImhError(f"{name}: dtype {t.dtype}, expected {dtype or self.dtype}")
 
     # ------------------------------------------------------------------ GEMM / conv
-    def _config(self, M, N, K, conv, flags):
+    # variant codes (include/imh.h): what each family can do, so that a tuning-table entry (keyed by shape only) is never
+    # handed a launch it rejects
+    _WS = (1464, 2464, 24128, 23256)          # wave-specialised (gemm_ring.hip)
+    _PP = (8256, 9128, 9256)                  # ping-pong (gemm_pp.hip)
+    _HALO = (7128, 7564)                      # LDS-halo conv3x3, stride 1
+
+    @classmethod
+    def _variant_ok(cls, bm, sp, flags, conv, stride, ln_pre):
+        plain = bm <= 128
+        if bm in cls._HALO:
+            return bool(conv) and stride == 1 and not flags & (L.GF_LN_ROW | L.GF_LN_COL | L.GF_VT_PERM)
+        if flags & (L.GF_VT_PERM | L.GF_LN_COL):
+            return plain and (sp == 1 or not flags & L.GF_LN_COL)
+        if flags & L.GF_LN_ROW:
+            if sp != 1 or conv:
+                return False
+            if plain:
+                return True
+            return bm in cls._WS if ln_pre else (bm in cls._PP or bm in (2464, 24128, 23256))
+        if bm in cls._PP and conv:
+            return False
+        return True
+
+    def _config(self, M, N, K, conv, flags, stride=1, ln_pre=False):
+        """tile variant of a launch: the tuning table's entry for the shape if that variant implements the launch's flags
+        (folded LayerNorm in either form, V^T permutation, conv stride), else the built-in heuristic -- in ONE place"""
         key = (M, N, K, int(conv))
-        if key in self.tuning:
-            return self.tuning[key]
+        # a fifth key field 1 = the entry for launches whose LayerNorm statistics are precomputed (other variants apply)
+        cfg = (self.tuning.get(key + (1,)) if ln_pre else None) or self.tuning.get(key)
+        if cfg is not None and self._variant_ok(cfg[0], cfg[2], flags, conv, stride, ln_pre):
+            return tuple(cfg)
         bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
         self.lib.imh_gemm_pick_config(M, N, K, C.byref(bm), C.byref(bn), C.byref(sp))
-        return bm.value, bn.value, sp.value
+        bm, bn, sp = bm.value, bn.value, sp.value
+        if flags & (L.GF_LN_ROW | L.GF_LN_COL) and (sp > 1 or cfg is not None):
+            # the statistics need the whole K range in one workgroup; a rejected table entry means a small-tile problem
+            bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
+        return bm, bn, sp
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             ln=None, _args_only=False):
+             ln=None, stats_out=False, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
-        ln = (s, c, eps) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
-        (w pre-scaled by gamma; the row statistics are taken inside the kernel's K loop)."""
+        ln = (s, c, eps[, stats]) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
+        (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' precomputed statistics
+        (csrc/imh_lnstats.h), None -> the kernel takes them inside its K loop.
+        stats_out=True: also return the row statistics of y for a LayerNorm-folding consumer -> (y, (tensor, slots)); they
+        come from the GEMM's own epilogue when the chosen variant has one, else from a row-statistics launch over y."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
         K = K if K is not None else x.shape[1]
@@ -176,18 +210,20 @@ class Ctx:
         n_out = N // 2 if flags & L.GF_GEGLU else N
         if out is None:
             out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
-        bm, bn, sp = cfg or self._config(M, N, K, 0, flags)
+        ln_stats = ln[3] if ln is not None and len(ln) > 3 else None
+        bm, bn, sp = cfg or self._config(M, N, K, 0, flags, ln_pre=ln_stats is not None)
         if _args_only:
             sp = 1
-        if ln is not None and cfg is None and (sp > 1 or (bm >= 256 and bm not in (8256, 9128, 9256, 2464, 24128, 23256))):   # the in-loop statistics live in the plain 2x2-wave tiles only
-            # (an explicit cfg is passed through: the C side rejects split-K / ring variants for the folded form)
-            bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
-        if ln is not None:           # (s, c fp32, eps); the caller sets GF_LN_ROW / GF_LN_COL in flags
+        keep_ln = ()
+        if ln is not None:           # (s, c fp32, eps[, stats]); the caller sets GF_LN_ROW / GF_LN_COL in flags
             a.ln_s, a.ln_c, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
-            ln = ln[:2]
+            keep_ln = (ln[0], ln[1])
+            if ln_stats is not None:
+                a.ln_stats, a.ln_slots = ln_stats[0].data_ptr(), int(ln_stats[1])
+                keep_ln += (ln_stats[0],)
         a.M, a.N, a.K = M, N, K
         a.ldx = ldx if ldx is not None else x.stride(0)
         a.ldw = ldw if ldw is not None else w.stride(0)
@@ -198,14 +234,34 @@ class Ctx:
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, flags, self.dt, 0, bm, bn
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
+        st = None
+        if stats_out and not _args_only:
+            wd = self.lib.imh_gemm_stats_slot_width(bm, bn)
+            if wd > 0 and N % wd == 0 and sp == 1 and not flags & (L.GF_GEGLU | L.GF_VT_PERM | L.GF_OUT_F32):
+                st = (self.new(M, N // wd, 2, dtype=torch.float32), N // wd)
+                a.ln_stats_out, a.ln_slots_out = st[0].data_ptr(), st[1]
         es = x.element_size()
         if _args_only:
-            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + tuple(ln or ())
+            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + keep_ln
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual) + tuple(ln or ()), shape=(M, N, K, 0, None),
+                   keep=(x, w, out, bias, rowadd, residual) + keep_ln + ((st[0],) if st else ()), shape=(M, N, K, 0, None),
                    epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
-                            rows_per_batch=rows_per_batch, cfg=(bm, bn, sp)))
+                            rows_per_batch=rows_per_batch, cfg=(bm, bn, sp), ln_pre=ln_stats is not None,
+                            ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None))
+        if stats_out:
+            if st is None:
+                st = self.row_stats(out.view(M, n_out) if out.dim() != 2 else out, descr=descr + ".row_stats")
+            return out, st
         return out
+
+    def row_stats(self, x, descr="row_stats"):
+        """LayerNorm statistics of token rows x [rows, C] in the hand-over format (one slot per row): the stand-alone
+        producer for rows whose writing GEMM variant has no statistics epilogue"""
+        rows, Cc = x.shape
+        st = self.new(rows, 1, 2, dtype=torch.float32)
+        self.ew(L.EW_ROW_STATS, st, a=x, n=rows, i=(Cc, x.stride(0), 0, 0, 0, 0), descr=descr,
+                nbytes=float(x.numel() * x.element_size()))
+        return st, 1
 
     def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
         """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch."""
@@ -218,7 +274,8 @@ class Ctx:
                 L.check(rc, "imh_plan_add")
             self.keep.extend(t for t in k1 + k2 if t is not None)
             self.tags.append((self.tag, L.OP_GEMM, descr, f1 + f2, b1 + b2, None,
-                              dict(dual=((a1.M, a1.N, a1.K, a1.flags), (a2.M, a2.N, a2.K, a2.flags)), cfg=tuple(cfg))))
+                              dict(dual=((a1.M, a1.N, a1.K, a1.flags), (a2.M, a2.N, a2.K, a2.flags)), cfg=tuple(cfg),
+                                   ln_pre=bool(a1.ln_stats), ln_slots=int(a1.ln_slots))))
             self._ops.append((L.OP_GEMM_DUAL, pair, self._cold(k1[:2] + k2[:2])))
         else:
             L.check(self.lib.imh_gemm_dual(C.byref(pair[0]), C.byref(pair[1]), self.stream()), descr)
@@ -237,13 +294,9 @@ class Ctx:
             raise L.ImhError(f"{descr}: x must be contiguous NHWC and w packed [Cout, 9*Cin]")
         if out is None:
             out = self.new(B, Ho, Wo, Cout)
-        bm, bn, sp = cfg or self._config(M, N, K, 1, 0)
-        if cfg is None and bm in (7128, 7564) and stride != 1:
-            # the table is keyed by (M, N, K): a stride-2 conv can share its key with a stride-1 conv of another
-            # resolution / batch; the LDS-halo kernel is stride-1 only -> heuristic tile for this one
-            hb, hn, hs = C.c_int(), C.c_int(), C.c_int()
-            self.lib.imh_gemm_pick_config(M, N, K, C.byref(hb), C.byref(hn), C.byref(hs))
-            bm, bn, sp = hb.value, hn.value, hs.value
+        # (the table is keyed by (M, N, K): a stride-2 conv can share its key with a stride-1 conv of another resolution /
+        # batch; the LDS-halo kernel is stride-1 only -> _config falls back to the heuristic tile for that one)
+        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride)
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
@@ -294,8 +347,12 @@ class Ctx:
         a = L.XAttnArgs()
         a.X, a.Wq, a.K, a.Vt, a.O = x.data_ptr(), wq.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
         a.K2, a.Vt2 = self._p(k2), self._p(vt2)
+        keep_st = ()
         if ln is not None:
             a.ln_s, a.ln_c, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+            if len(ln) > 3 and ln[3] is not None:
+                a.ln_stats, a.ln_slots = ln[3][0].data_ptr(), int(ln[3][1])
+                keep_st = (ln[3][0],)
         a.B, a.H, a.Lq, a.C = B, H, Lq, C_
         a.Lk, a.Lk_pad, a.Lk2, a.Lk2_pad = Lk, Lk_pad, Lk2, Lk2_pad
         a.ldx, a.ldw, a.ldk, a.ldvt, a.ldk2, a.ldvt2, a.ldo = x.stride(0), wq.stride(0), ldk, ldvt, ldk2, ldvt2, out.stride(0)
@@ -306,7 +363,7 @@ class Ctx:
         fl = 2.0 * M * C_ * C_ + 4.0 * B * H * Lq * (Lk + Lk2) * 64
         by = es * (2 * M * C_ + C_ * C_ + 2 * B * (Lk + Lk2) * C_)
         self._emit(L.OP_XATTN, a, descr=descr, flops=fl, nbytes=by,
-                   keep=(x, wq, k, vt, out, k2, vt2, scale2_tab, step) + tuple((ln or ())[:2]))
+                   keep=(x, wq, k, vt, out, k2, vt2, scale2_tab, step) + tuple((ln or ())[:2]) + keep_st)
         return out
 
     def attention_small(self, q, k, v, B, H, Lq, Lk, dq, dv, scale, out=None, descr="attention_small"):

@@ -10,11 +10,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
-EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX = range(10)
+(EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX,
+ EW_ROW_STATS) = range(11)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 
@@ -22,6 +23,7 @@ _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
                 ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
+                ("ln_stats", _vp), ("ln_stats_out", _vp), ("ln_slots", _i32), ("ln_slots_out", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
@@ -39,7 +41,7 @@ class AttnArgs(C.Structure):
 
 
 class XAttnArgs(C.Structure):
-    _fields_ = [("X", _vp), ("Wq", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
+    _fields_ = [("X", _vp), ("Wq", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32), ("ln_stats", _vp), ("ln_slots", _i32),
                 ("K", _vp), ("Vt", _vp), ("K2", _vp), ("Vt2", _vp), ("O", _vp),
                 ("B", _i32), ("H", _i32), ("Lq", _i32), ("C", _i32), ("Lk", _i32), ("Lk_pad", _i32), ("Lk2", _i32),
                 ("Lk2_pad", _i32),
@@ -77,6 +79,7 @@ SYMBOLS = [
     ("imh_gemm_pick_config", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]),
     ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("imh_gemm_stats_slot_width", C.c_int, [C.c_int, C.c_int]),
     ("imh_attention", C.c_int, [C.POINTER(AttnArgs), _vp]),
     ("imh_cross_attention", C.c_int, [C.POINTER(XAttnArgs), _vp]),
     ("imh_attention_small", C.c_int, [C.POINTER(SmallAttnArgs), _vp]),

@@ -18,6 +18,7 @@ torch is used for parameter storage and device memory only.  ``emit_forward`` re
 forward into a ``Ctx`` (plan / hipGraph); ``forward`` is the eager drop-in signature.
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Tuple
 
@@ -34,6 +35,11 @@ from .ctx import Ctx
 # operand fragments, and normalises in its epilogue -- 210 LayerNorm launches and 0.84 GB of HBM traffic per forward
 # disappear.  False = the stand-alone LayerNorm kernel in front of every consumer (A/B and debugging).
 FOLD_LAYERNORM = True
+# With the fold: the GEMM that WRITES a LayerNorm input (proj_in, to_out + residual, ff.out + residual) leaves the rows'
+# (sum, M2) slot partials behind from its epilogue (csrc/imh_lnstats.h) and the consumers merge them in their prologues,
+# instead of every consumer re-deriving the statistics inside its K loop (64-fold redundant for ff.net.0: every column tile
+# of a row block repeated them).  False = in-loop statistics (A/B; IMH_LN_STATS=0 in the environment).
+LN_STATS_HANDOVER = os.environ.get("IMH_LN_STATS", "1") != "0"
 
 
 @dataclass
@@ -176,14 +182,14 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), Dropout(), Linear(dim * 4, dim)])
 
-    def emit(self, ctx, x, residual, ln=None):
+    def emit(self, ctx, x, residual, ln=None, ln_stats=None, want_stats=False):
         if ln is None:
             w1, b1 = self.net[0].packed(ctx)
             g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU, descr="ff.geglu")
         else:       # x un-normalised, LayerNorm `ln` folded into the (interleaved) GEGLU projection
             w1, b1, s1, c1 = self.net[0].packed_ln(ctx, ln)
-            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU | L.GF_LN_ROW, ln=(s1, c1, ln.eps), descr="ff.geglu")
-        out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out")
+            g = ctx.gemm(x, w1, bias=b1, flags=L.GF_GEGLU | L.GF_LN_ROW, ln=(s1, c1, ln.eps, ln_stats), descr="ff.geglu")
+        out = ctx.gemm(g, _w(self.net[2], ctx), bias=_b(self.net[2], ctx), residual=residual, descr="ff.out", stats_out=want_stats)
         ctx.free(g)
         return out
 
@@ -202,21 +208,44 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = Norm(dim, 1e-5)
         self.ff = FeedForward(dim)
 
-    def emit(self, ctx, h, B, L_, kv, st):
+    def fused(self, L_):
+        """the folded-LayerNorm form applies (both processors are the HIP ones, 64-aligned token count)"""
+        return FOLD_LAYERNORM and isinstance(self.attn1.processor, AttnProcessor2_0) \
+            and isinstance(self.attn2.processor, IPAttnProcessor2_0) and L_ % 64 == 0
+
+    def emit(self, ctx, h, B, L_, kv, st, stats=None, want_stats=False):
+        """h: the residual stream [B*L, C] (consumed).  stats = row statistics of h from the GEMM that wrote it (or None);
+        want_stats: return (h3, statistics of h3) for the next block's norm1."""
         p1, p2 = self.attn1.processor, self.attn2.processor
         if not hasattr(p1, "emit") or not hasattr(p2, "emit"):
             raise L.ImhError("a non-HIP attention processor is installed; the fused forward needs "
                              "imagharmony_amd.attention_processor processors")
         ip2 = isinstance(p2, IPAttnProcessor2_0)
-        if FOLD_LAYERNORM and isinstance(p1, AttnProcessor2_0) and ip2 and L_ % 64 == 0:
-            # LayerNorm never materialises: every consumer GEMM reads the residual stream itself
-            h1 = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1)
+        if self.fused(L_):
+            # LayerNorm never materialises: every consumer GEMM reads the residual stream itself, and (LN_STATS_HANDOVER)
+            # takes the rows' statistics from the epilogue of the GEMM that wrote it
+            ho = LN_STATS_HANDOVER
+            if not ho:
+                stats = None
+            r = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1, ln_stats=stats, want_stats=ho)
+            h1, s1 = r if ho else (r, None)
             ctx.free(h)
-            h2 = p2.emit(ctx, self.attn2, h1, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab, ln=self.norm2)
+            if stats is not None:
+                ctx.free(stats[0])
+            r = p2.emit(ctx, self.attn2, h1, B, L_, residual=h1, kv=kv, step=st.step, scale_tab=st.ip_scale_tab, ln=self.norm2,
+                        ln_stats=s1, want_stats=ho)
+            h2, s2 = r if ho else (r, None)
             ctx.free(h1)
-            h3 = self.ff.emit(ctx, h2, residual=h2, ln=self.norm3)
+            if s1 is not None:
+                ctx.free(s1[0])
+            r = self.ff.emit(ctx, h2, residual=h2, ln=self.norm3, ln_stats=s2, want_stats=ho and want_stats)
+            h3, s3 = r if (ho and want_stats) else (r, None)
             ctx.free(h2)
-            return h3
+            if s2 is not None:
+                ctx.free(s2[0])
+            return (h3, s3) if want_stats else h3
+        if stats is not None:
+            ctx.free(stats[0])
         n = _ln(ctx, self.norm1, h, "norm1")
         h1 = p1.emit(ctx, self.attn1, n, B, L_, residual=h)
         ctx.free(n); ctx.free(h)
@@ -227,7 +256,7 @@ class BasicTransformerBlock(nn.Module):
         n = _ln(ctx, self.norm3, h2, "norm3")
         h3 = self.ff.emit(ctx, n, residual=h2)
         ctx.free(n); ctx.free(h2)
-        return h3
+        return (h3, None) if want_stats else h3
 
 
 class Transformer2DModel(nn.Module):
@@ -247,10 +276,15 @@ class Transformer2DModel(nn.Module):
         x2 = x.view(B * L_, C_)
         n = ctx.groupnorm(x.view(B, L_, C_), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps,
                           silu=False, descr="t2d.norm")
-        h = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in")
+        blocks = list(self.transformer_blocks)
+        ho = LN_STATS_HANDOVER and bool(blocks) and blocks[0].fused(L_)
+        r = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in", stats_out=ho)
+        h, stats = r if ho else (r, None)
         ctx.free(n)
-        for blk, kv in zip(self.transformer_blocks, kvs):
-            h = blk.emit(ctx, h, B, L_, kv, st)
+        for i, (blk, kv) in enumerate(zip(blocks, kvs)):
+            more = ho and i + 1 < len(blocks) and blocks[i + 1].fused(L_)
+            r = blk.emit(ctx, h, B, L_, kv, st, stats=stats, want_stats=more)
+            h, stats = r if more else (r, None)
         out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out")
         ctx.free(h); ctx.free(x)
         return out.view(B, Hh, Ww, C_)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 3
+#define IMH_ABI_VERSION 4
 
 enum imh_status {
     IMH_OK = 0,
@@ -81,14 +81,29 @@ typedef struct imh_gemm_args {
     /* LayerNorm folded into the contraction (IMH_GF_LN_ROW: X rows are the un-normalised tokens; IMH_GF_LN_COL:
      * W rows are).  With W pre-scaled by gamma:  y = rstd * (acc - mean * ln_s) + ln_c  (exact algebra of
      * LN(x) W^T; BasicTransformerBlock.norm1/2/3 never materialise and cost no launch).  (mean, rstd) of every
-     * token row are computed INSIDE the kernel's K loop from the operand fragments the MFMAs consume (fp32 sum and
-     * sum of squares over K), so no statistics buffer exists.  ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k
-     * W[.,k] (fp32; row form: per output column n, column form: per output row m).  Plain 64/128 tiles (both
-     * forms), the ping-pong variants bm = 8256 / 9128 / 9256 or the wave-specialised ones 1464 / 2464 / 24128 / 23256
-     * (row form; there the producer waves sum the rows from LDS); splits == 1, conv == 0. */
+     * token row come either from `ln_stats` (below) or, with ln_stats == NULL, from inside the kernel's K loop (fp32
+     * sum and sum of squares over K of the operand fragments the MFMAs consume).  ln_s = sum_k gamma_k W[.,k],
+     * ln_c = sum_k beta_k W[.,k] (fp32; row form: per output column n, column form: per output row m).
+     * In-loop statistics: plain 64/128 tiles (both forms), the ping-pong variants bm = 8256 / 9128 / 9256 and the
+     * wave-specialised ones with four producer waves 2464 / 24128 / 23256 (row form; the producer waves sum the rows
+     * from LDS).  Precomputed statistics: plain tiles (both forms) and every wave-specialised variant (row form).
+     * splits == 1, conv == 0. */
     const float* ln_s;
     const float* ln_c;
     float ln_eps;
+    /* Row-statistics hand-over between the GEMM that WRITES a LayerNorm input (attn.to_out + residual,
+     * attention_processor.py:320-329,453-462; ff.net.2 + residual; proj_in) and the launches that consume it folded.
+     * Format (csrc/imh_lnstats.h): [rows][slots][2] fp32 = (sum, M2 about the slot mean) of `width` consecutive
+     * channels per slot, taken from the values as rounded to the output dtype; slots merge by Chan's formula (no
+     * E[x^2] - mean^2 cancellation).
+     *   ln_stats / ln_slots          input: partials of the token rows of a IMH_GF_LN_ROW / _COL launch (K % slots == 0)
+     *   ln_stats_out / ln_slots_out  output: partials of THIS launch's Y rows; ln_slots_out must equal
+     *                                N / imh_gemm_stats_slot_width(bm, bn) (N a multiple of that width, plain T output,
+     *                                no GEGLU / V^T permutation / fp32 output / split-K / conv)
+     * IMH_EW_ROW_STATS writes the same format (one slot per row) for rows no statistics epilogue covers. */
+    const float* ln_stats;
+    float* ln_stats_out;
+    int32_t ln_slots, ln_slots_out;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -114,6 +129,9 @@ int imh_gemm(const imh_gemm_args* a, void* stream);
  * In a plan: kind IMH_OP_GEMM_DUAL with args = imh_gemm_args[2]. */
 int imh_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, void* stream);
 int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
+/* channels per statistics slot written by tile variant (bm, bn) through ln_stats_out; 0 = the variant has no
+ * statistics epilogue (use IMH_EW_ROW_STATS on its output instead) */
+int imh_gemm_stats_slot_width(int bm, int bn);
 size_t imh_gemm_workspace_bytes(int M, int N, int splits);
 
 /* ---- attention, head_dim 64 -------------------------------------------------------------
@@ -170,6 +188,8 @@ typedef struct imh_xattn_args {
     const float* ln_s;
     const float* ln_c;
     float ln_eps;
+    const float* ln_stats;   /* with ln_s: precomputed row statistics of X ([B*Lq][ln_slots][2], see imh_gemm_args); NULL -> taken in the kernel */
+    int32_t ln_slots;
     const void* K;
     const void* Vt;
     const void* K2;
@@ -243,7 +263,8 @@ enum imh_ew_op {
     IMH_EW_STEP_SET = 7,  /* *y(int32) = i1 ? i0 : *y + 1 : the device-side step counter */
     IMH_EW_CFG_RESCALE = 8, /* y[s] = f3 * std(eps_text_s) / std(eps_cfg_s) + 1 - f3 (rescale_noise_cfg, custom_pipelines.py:351-354);
                              * a = noise prediction NHWC [2 i0, i1, 4], f2 = guidance scale; IMH_EW_CFG_STEP reads y through `w` */
-    IMH_EW_SOFTMAX = 9      /* y[r,:] (T) = softmax(f0 * a[r,:]) with a fp32 (VAE mid-block attention); i0 rows, i1 cols, i2 / i3 leading dims */
+    IMH_EW_SOFTMAX = 9,     /* y[r,:] (T) = softmax(f0 * a[r,:]) with a fp32 (VAE mid-block attention); i0 rows, i1 cols, i2 / i3 leading dims */
+    IMH_EW_ROW_STATS = 10   /* y[r] (fp32 pair) = (sum, M2) of a[r, 0:i0] (row stride i1), n rows: LayerNorm statistics in the ln_stats format, one slot */
 };
 
 typedef struct imh_ew_args {

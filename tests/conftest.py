@@ -59,6 +59,17 @@ def cmp_cfg_golden(y, g, case, what, tol, name=None):
     return r_rows
 
 
+def ref_row_stats(x, slots):
+    """row statistics of x [rows, C] in the hand-over format of csrc/imh_lnstats.h, computed with torch in fp64:
+    [rows, slots, 2] fp32 = (sum, sum of squared deviations from the slot mean) of every run of C / slots channels"""
+    import torch
+    rows, C = x.shape
+    v = x.double().view(rows, slots, C // slots)
+    s = v.sum(-1)
+    m2 = (v - v.mean(-1, keepdim=True)).pow(2).sum(-1)
+    return torch.stack([s, m2], -1).float().contiguous()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -1,0 +1,156 @@
+"""GPU: the LayerNorm-statistics hand-over (csrc/imh_lnstats.h) -- the GEMM that writes a LayerNorm input leaves per-row
+(sum, M2) slot partials behind from its epilogue, the consumers (ff.net.0 on the wave-specialised kernel, [Q|K] + V^T, the
+fused cross-attention's to_q) merge them instead of re-deriving the statistics in their K loops.  Reference math: diffusers
+BasicTransformerBlock.norm1/2/3 = torch LayerNorm, here F.layer_norm in fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ref_row_stats
+from test_gpu_ops import DEV, DTYPES, EPS, L, assert_close, ctx_for, rnd, vt_unpermute  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _norm(K):
+    norm = torch.nn.LayerNorm(K, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3)))
+        norm.bias.copy_(0.3 * torch.randn(K, generator=torch.Generator().manual_seed(4)))
+    return norm
+
+
+def _check_stats(st, slots, y, what):
+    ref = ref_row_stats(y.float(), slots).to(st.device)
+    assert st.shape == ref.shape, (st.shape, ref.shape)
+    width = y.shape[1] // slots
+    s_err = (st[..., 0] - ref[..., 0]).abs().max().item()
+    s_scale = y.float().abs().max().item() * width
+    m_rel = ((st[..., 1] - ref[..., 1]).abs() / (ref[..., 1].abs() + 1e-6 * width * y.float().pow(2).mean().item())).max().item()
+    assert s_err <= 2e-6 * s_scale and m_rel <= 2e-4, f"{what}: sum err {s_err:.3e} (scale {s_scale:.3e}), M2 rel err {m_rel:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,width", [((2464, 160, 1), 80), ((1464, 160, 1), 80), ((24128, 160, 1), 80), ((24128, 128, 1), 64),
+                                       ((23256, 160, 1), 80), ((64, 64, 1), 32), ((128, 64, 1), 32), ((64, 128, 1), 64), ((128, 128, 1), 64)])
+def test_statistics_epilogue(L, dtype, cfg, width):
+    """ln_stats_out of every variant that has the epilogue, in the two forms the forward uses (proj_in: bias only; to_out /
+    ff.out: bias + residual), ragged M included: slot sums / M2 of the values AS STORED (rounded to the output dtype)"""
+    ctx = ctx_for(dtype)
+    assert ctx.lib.imh_gemm_stats_slot_width(cfg[0], cfg[1]) == width
+    for (M, N, K) in [(256, 640, 128), (300, 1280, 192), (2048, 1280, 640)]:
+        if N % width:
+            continue
+        x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+        bias, res = rnd(N, dtype=dtype, seed=5), (rnd(M, N, dtype=dtype, seed=6) * 1.5 + 0.5).contiguous()
+        for residual in (None, res):
+            y, (st, slots) = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, stats_out=True)
+            assert slots == N // width
+            ref = x.float() @ w.float().t() + bias.float() + (residual.float() if residual is not None else 0.0)
+            assert_close(y, ref, dtype, f"gemm {cfg} {(M, N, K)}")
+            _check_stats(st, slots, y, f"statistics epilogue {cfg} {(M, N, K)} residual={residual is not None}")
+            y2, (st2, _) = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, stats_out=True)
+            assert torch.equal(y2, y) and torch.equal(st2, st)
+            for t in (y, st, y2, st2):
+                ctx.free(t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_statistics_fallback_kernel_and_rejections(L, dtype):
+    """variants without the epilogue hand the statistics over through the row-statistics launch (one slot per row); the C
+    side refuses ln_stats_out where no epilogue exists"""
+    ctx = ctx_for(dtype)
+    M, N, K = 300, 640, 256
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    for cfg in [(256, 128, 1), (3064, 64, 1), (64, 64, 2)]:
+        y, (st, slots) = ctx.gemm(x, w, cfg=cfg, stats_out=True)
+        assert slots == 1
+        _check_stats(st, 1, y, f"row-statistics kernel behind {cfg}")
+    a = ctx.gemm(x, w, cfg=(256, 128, 1), _args_only=True)[0]
+    a.ln_stats_out, a.ln_slots_out = st.data_ptr(), 1
+    assert ctx.lib.imh_gemm(a, ctx.stream()) == -1 and b"ln_stats_out" in ctx.lib.imh_last_error()
+
+
+def _stats_for(ctx, x, how):
+    """the three producers a consumer can meet: a GEMM epilogue's 80- / 32-wide slots (here minted with torch in the same
+    format), or the one-slot row-statistics kernel"""
+    K = x.shape[1]
+    if how == "kernel":
+        return ctx.row_stats(x)
+    slots = K // how
+    return ref_row_stats(x.float(), slots).to(DEV), slots
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(23256, 160, 1), (2464, 160, 1), (1464, 160, 1), (24128, 160, 1), (24128, 128, 1), (128, 128, 1), (64, 64, 1)])
+@pytest.mark.parametrize("how", [80, 32, "kernel"])
+def test_folded_layernorm_with_precomputed_statistics(L, dtype, cfg, how):
+    """LN(x) W^T (+ GEGLU) with the statistics taken from the hand-over buffer, row form, every consuming variant; x with a
+    row mean of 2 sigma"""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    for (M, N, K) in [(512, 640, 320), (300, 960, 640), (2048, 2560, 1280)]:
+        x = (rnd(M, K, dtype=dtype, seed=1) * 1.5 + 3.0).contiguous()
+        w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+        norm = _norm(K)
+        full = (F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()).to(DEV)
+        wg, s, c = fold_ln(w, norm, ctx)
+        st = _stats_for(ctx, x, how)
+        y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=cfg)
+        assert_close(y, full, dtype, f"LN (precomputed, {how}) {cfg} {(M, N, K)}", k=6.0)
+        g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5, st), cfg=cfg)
+        assert_close(g, full[:, 0::2] * F.gelu(full[:, 1::2]), dtype, f"LN (precomputed, {how}) + GEGLU {cfg} {(M, N, K)}", k=8.0)
+        assert torch.equal(g, ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5, st), cfg=cfg))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(64, 64), (128, 64), (64, 128), (128, 128)])
+def test_dual_projection_with_precomputed_statistics(L, dtype, cfg):
+    """self-attention's [Q|K] (row form) + V^T (column form, V^T layout) launch with the statistics handed over"""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    for (M, N, K) in [(192, 256, 128), (2048, 1280, 640)]:
+        x = (rnd(M, K, dtype=dtype, seed=1) * 1.5 + 3.0).contiguous()
+        w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+        norm = _norm(K)
+        ref = (F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()).to(DEV)
+        wg, s, c = fold_ln(w, norm, ctx)
+        for how in (32 if K % 32 == 0 else 64, "kernel"):
+            st = _stats_for(ctx, x, how)
+            bm, bn = cfg
+            y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(bm, bn, 1))
+            assert_close(y, ref, dtype, f"row form {cfg}", k=6.0)
+            yt = ctx.gemm(wg, x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(s, c, 1e-5, st), cfg=(bm, 128, 1))
+            assert_close(vt_unpermute(yt), ref.t(), dtype, f"column form {cfg}", k=6.0)
+            y2, yt2 = ctx.gemm_dual(dict(x=x, w=wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st)),
+                                    dict(x=wg, w=x, flags=L.GF_LN_COL | L.GF_VT_PERM, ln=(s, c, 1e-5, st)), cfg=(bm, 128))
+            assert torch.equal(y2, ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(bm, 128, 1))) and torch.equal(yt2, yt)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_large_common_offset_rows(L, dtype):
+    """|mean| >> std (x = 50 + N(0, 0.1), as stored).  The hand-over statistics are Chan-merged (sum, M2) pairs:
+    no E[x^2] - mean^2 cancellation, the folded result matches torch's LayerNorm + Linear; the legacy in-loop form (sum and
+    sum of squares in fp32) is only required to stay finite and bounded here -- it is not on the forward's path any more."""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    M, N, K = 256, 640, 1280
+    x = (50.0 + 0.1 * rnd(M, K, dtype=torch.float32, seed=1)).to(dtype).contiguous()
+    x[3] = 50.0                                            # and one zero-variance row
+    w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+    norm = _norm(K)
+    ref = (F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()).to(DEV)
+    wg, s, c = fold_ln(w, norm, ctx)
+    # statistics from a real producer: y = 0 @ W + residual(x) through the wave-specialised kernel's epilogue
+    z = torch.zeros(M, 64, dtype=dtype, device=DEV)
+    xx, st = ctx.gemm(z, torch.zeros(K, 64, dtype=dtype, device=DEV), residual=x, cfg=(2464, 160, 1), stats_out=True)
+    assert torch.equal(xx, x) and st[1] == K // 80
+    for cfg in [(2464, 160, 1), (23256, 160, 1), (128, 128, 1)]:
+        y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=cfg)
+        # the mean term rstd * mean * s_n is ~ 500 sigma of the result: its fp32 cancellation against acc bounds the error
+        err = (y.float() - ref).abs().max().item()
+        assert torch.isfinite(y.float()).all() and err < 0.15, f"{cfg}: max err {err:.3e} with handed-over statistics"
+    y_old = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(128, 128, 1))
+    assert torch.isfinite(y_old.float()).all()
+    print(f"{dtype}: handed-over statistics max err {err:.3e}; in-loop statistics max err {(y_old.float() - ref).abs().max().item():.3e} "
+          f"(result scale {ref.abs().max().item():.2f})")

@@ -251,14 +251,27 @@ def test_attention_cross_ip(L, dtype, B, H, Lq, nt, nip):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,Lq,nt,nip,ln", [(2, 2, 256, 77, 4, True), (1, 20, 128, 77, 16, True), (2, 5, 100, 77, 32, False),
-                                               (1, 10, 192, 130, 0, True), (2, 20, 1024, 77, 4, True), (2, 10, 4096, 77, 0, False)])
-def test_fused_cross_attention(L, dtype, B, H, Lq, nt, nip, ln):
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,Lq,nt,nip,ln", [(2, 2, 256, 77, 4, 1), (1, 20, 128, 77, 16, 2), (2, 5, 100, 77, 32, 0), (2, 4, 100, 77, 32, 2),
+                                               (1, 10, 192, 130, 0, 1), (2, 20, 1024, 77, 4, 2), (2, 20, 1024, 77, 0, 3), (2, 10, 4096, 77, 0, 0)])
+def test_fused_cross_attention(L, dtype, mode, B, H, Lq, nt, nip, ln):
     """csrc/xattn.hip -- to_q (+ folded LayerNorm) + text attention (+ image-prompt attention, text + s * ip) in ONE
     launch against the same ops in fp32 torch: q = LN(x) Wq^T rounded to the compute dtype (as attn.to_q does), then
-    SDPA per key set.  K caches carry the head dims in the permuted order the kernel's hand-over expects."""
+    SDPA per key set.  K caches carry the head dims in the permuted order the kernel's hand-over expects.
+    mode (imh_debug_set key 3): 1 = one head per workgroup; 2 / 3 / 4 = two heads per workgroup with 0 / 2 / 4 producer
+    waves (an odd head count always takes the one-head kernel).  ln: 0 none, 1 statistics in the K loop, 2 / 3 = handed-over
+    statistics in 32-wide slots / from the row-statistics kernel."""
+    from conftest import ref_row_stats
     from imagharmony_amd.attention_processor import fold_ln
     ctx = ctx_for(dtype)
+    assert L.load().imh_debug_set(3, mode) == 0
+    try:
+        _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_stats, fold_ln)
+    finally:
+        L.load().imh_debug_set(3, 0)
+
+
+def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_stats, fold_ln):
     C_ = H * 64
     x = (rnd(B * Lq, C_, dtype=dtype, seed=1) * 1.3 + (0.7 if ln else 0.0)).contiguous()
     wq = rnd(C_, C_, dtype=torch.float32, seed=6, scale=C_ ** -0.5)
@@ -276,7 +289,8 @@ def test_fused_cross_attention(L, dtype, B, H, Lq, nt, nip, ln):
             norm.weight.copy_(1 + 0.2 * torch.randn(C_, generator=torch.Generator().manual_seed(3)))
             norm.bias.copy_(0.3 * torch.randn(C_, generator=torch.Generator().manual_seed(4)))
         wg, s_, c_ = fold_ln(wq, norm, ctx)
-        lnq = (s_, c_, 1e-5)
+        st = None if ln == 1 else ((ref_row_stats(x.float(), C_ // 32).to(DEV), C_ // 32) if ln == 2 else ctx.row_stats(x))
+        lnq = (s_, c_, 1e-5, st)
         xn = F.layer_norm(x.float(), (C_,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
         q_ref = (xn @ wq.to(DEV).t()).to(dtype)
     else:

@@ -19,7 +19,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import record_parity, rel_rms
+from conftest import record_parity, ref_row_stats, rel_rms
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -281,7 +281,9 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
                 norm = _rand_norm(K1)
                 wqk_g, s1, c1 = fold_ln(wqk.float(), norm, ctx)
                 wv_g, s2, c2 = fold_ln(wv.float(), norm, ctx)
-                qk, vt = ctx.gemm_dual(dict(x=x, w=wqk_g, flags=f1, ln=(s1, c1, 1e-5)), dict(x=wv_g, w=x, flags=f2, ln=(s2, c2, 1e-5)),
+                # the forward hands the rows' statistics over from the producing GEMM's epilogue: same slot count here
+                st = (ref_row_stats(x.float(), epi["ln_slots"]).to(DEV), epi["ln_slots"]) if epi.get("ln_pre") else None
+                qk, vt = ctx.gemm_dual(dict(x=x, w=wqk_g, flags=f1, ln=(s1, c1, 1e-5, st)), dict(x=wv_g, w=x, flags=f2, ln=(s2, c2, 1e-5, st)),
                                        cfg=epi["cfg"], descr=descr)
                 xn = F.layer_norm(x.float(), (K1,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
             else:
@@ -322,14 +324,21 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
                 x = (x.float() * 1.5 + 2.0).to(dtype)
                 norm = _rand_norm(K)
                 wg, s_, c_ = fold_ln(w.float(), norm, ctx)
+                st = (ref_row_stats(x.float(), epi["ln_slots"]).to(DEV), epi["ln_slots"]) if epi.get("ln_pre") else None
                 y = ctx.gemm(x, wg, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
-                             flags=epi["flags"], ln=(s_, c_, 1e-5), cfg=(bm, bn, sp), descr=descr)
+                             flags=epi["flags"], ln=(s_, c_, 1e-5, st), cfg=(bm, bn, sp), descr=descr)
                 xn = F.layer_norm(x.float(), (K,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
                 _close(y, _ref_epilogue(xn @ w.float().t(), epi, bias, residual, rowadd, L), dtype, f"{descr} {shape} {epi}", k=6.0)
             else:
                 assert not epi["flags"] & L.GF_LN_COL
                 y = ctx.gemm(x, w, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
-                             flags=epi["flags"], cfg=(bm, bn, sp), descr=descr)
+                             flags=epi["flags"], cfg=(bm, bn, sp), descr=descr, stats_out=bool(epi.get("stats_out")))
+                if epi.get("stats_out"):       # the launches that leave LayerNorm statistics behind: check them as stored
+                    y, (st, slots) = y
+                    want = ref_row_stats(y.float(), slots).to(DEV)
+                    assert (st[..., 0] - want[..., 0]).abs().max().item() <= 2e-6 * y.float().abs().max().item() * (N // slots)
+                    assert ((st[..., 1] - want[..., 1]).abs() / (want[..., 1] + 1e-3)).max().item() <= 2e-4
+                    ctx.free(st)
                 ref = _ref_epilogue(x.float() @ w.float().t(), epi, bias, residual, rowadd, L)
                 _close(y, ref, dtype, f"{descr} {shape} {epi}")
         ctx.free(y)
@@ -349,7 +358,7 @@ def test_every_tuning_table_entry_vs_matmul():
     for dtype in (torch.bfloat16, torch.float16):
         ctx = Ctx(DEV, dtype)
         for key, cfg in table.items():
-            M, N, K, conv = (int(v) for v in key.split(","))
+            M, N, K, conv = (int(v) for v in key.split(",")[:4])
             if cfg[0] in (7128, 7564):        # the LDS-halo conv kernel has no plain-GEMM form: covered with its real geometry above
                 assert conv == 1
                 continue

@@ -156,12 +156,12 @@ def test_header_enums_match_python_constants():
     hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
     vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
     vals.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s+(\d+)", hdr)})
-    assert len([k for k in vals if k.startswith("IMH_EW_")]) == 10
+    assert len([k for k in vals if k.startswith("IMH_EW_")]) == 11
     for k, v in vals.items():
         py = k[len("IMH_"):]
         if hasattr(lib, py):
             assert getattr(lib, py) == v, k
-    for name in ("EW_TIMESTEP", "EW_CONV_IN", "EW_CFG_STEP", "EW_STEP_SET", "EW_CFG_RESCALE", "EW_SOFTMAX"):
+    for name in ("EW_TIMESTEP", "EW_CONV_IN", "EW_CFG_STEP", "EW_STEP_SET", "EW_CFG_RESCALE", "EW_SOFTMAX", "EW_ROW_STATS"):
         assert vals["IMH_" + name] == getattr(lib, name)
 
 
@@ -249,7 +249,7 @@ def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
     table = json.load(open(os.path.join(ROOT, "imagharmony_amd", "tuning.json")))
     assert len(table) >= 30
     for key, (bm, bn, splits) in table.items():
-        M, N, K, conv = (int(v) for v in key.split(","))
+        M, N, K, conv = (int(v) for v in key.split(",")[:4])      # (an optional fifth field 1: the entry for precomputed LN statistics)
         assert splits >= 1 and K % 64 == 0, key
         if (bm, bn) in halo:
             assert conv == 1, key
