@@ -222,6 +222,7 @@ int imh_debug_set(int key, int value) {
     if (key == 0) { g_attn_force_nw = value; return IMH_OK; }
     if (key == 2) { g_xcd_mode = value; return IMH_OK; }
     if (key == 3) { g_xattn_mode = value; return IMH_OK; }
+    if (key == 4) { g_attn_mode = value; return IMH_OK; }
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;
 }

@@ -20,6 +20,7 @@
 namespace imh {
 
 int g_attn_force_nw = 0;   // retired tuning knob (imh_debug_set key 0): only the 4-wave workgroup is built
+int g_attn_mode = 0;       // imh_debug_set key 4: 0 auto, 1 in-order key loop (attn_core), 2 software-pipelined key loop (attn_core_pipe; one key set)
 
 // NW waves per workgroup (32 queries each); the launcher uses NW = 4.
 // NPASS = 1: single key set (self-attention, text-only cross-attention): no second accumulator, lower register
@@ -76,6 +77,50 @@ __global__ __launch_bounds__(64 * NW, (NPASS == 1 && NW == 4) ? 3 : 2) void attn
     attn_core<T, NW, NPASS>(p, smem, qf, b, h, wave, lane, item, fin);
     attn_store<T, NW>(p, qs, fin, b, h, q0, wave, lane);
     if (!ATT_TIMING) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+}
+
+
+// The same workgroup shape with the software-pipelined key loop (imh_attn_core.h attn_core_pipe): one key set only (the
+// self-attention of AttnProcessor2_0), 4-slot K / V^T ring (64 KB -> two workgroups per CU, 256 registers per lane).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
+    constexpr int NW = 4;
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // ATT_PIPE_STAGES * 16 KB
+    unsigned char* qs = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31;
+    const int hi = lane >> 5;
+    const int gx = (p.Lq + 32 * NW - 1) / (32 * NW);
+    const int items = gx * p.H * p.B;
+    const int per = (items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    const int hb = item / gx, qblk = item - hb * gx;
+    const int b = hb / p.H, h = hb - b * p.H;
+    const int q0 = qblk * (32 * NW);
+    v8 qf[4];
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            const int ch = stage_chunk_x(row, lane);
+            const T* src = (const T*)p.Q + ((size_t)b * p.Lq + min(q0 + row, p.Lq - 1)) * p.ldq + h * 64 + ch * 8;
+            glds16(src, qs + (wave * 32 + i * 8) * 128);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int row = wave * 32 + l32;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qs + tile_off(row, sd * 2 + hi, swz_x(row)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    f32x16 fin[2];
+    attn_core_pipe<T>(p, smem, qf, b, h, wave, lane, fin);
+    attn_store<T, NW>(p, qs, fin, b, h, q0, wave, lane);
+    tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
 }
 
 // ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
@@ -246,6 +291,14 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     constexpr int nw = 4;
     const int items = ((p.Lq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
     dim3 grid(8 * ((items + 7) / 8));
+    if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
+        const int lds = ATT_PIPE_STAGES * 2 * ATT_TILE_BYTES;
+        if (dtype == IMH_DT_BF16) { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<bf16_t>, lds);
+                                    hipLaunchKernelGGL((attn_pipe_kernel<bf16_t>), grid, dim3(256), lds, stream, p); }
+        else { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<f16_t>, lds);
+               hipLaunchKernelGGL((attn_pipe_kernel<f16_t>), grid, dim3(256), lds, stream, p); }
+        return check_launch("attn_pipe_kernel");
+    }
 #define IMH_ATT_LAUNCH(TT, NWV) do { if (p.K2) hipLaunchKernelGGL((attn_kernel<TT, NWV, 2>), grid, dim3(64 * NWV), 0, stream, p); \
         else hipLaunchKernelGGL((attn_kernel<TT, NWV, 1>), grid, dim3(64 * NWV), 0, stream, p); } while (0)
     if (dtype == IMH_DT_BF16) IMH_ATT_LAUNCH(bf16_t, 4);

@@ -4,6 +4,7 @@
 #pragma once
 #include "imh_common.h"
 #include "imh_kernels.h"
+#include <type_traits>
 
 namespace imh {
 
@@ -228,6 +229,328 @@ __device__ __forceinline__ void attn_core(const AttnParams& p, unsigned char* sm
             for (int r = 0; r < 16; ++r) fin[dt][r] += o[dt][r] * inv;
     }
 
+}
+
+// One 64-key tile that is already RESIDENT in LDS (K rows at ks, V^T rows at vs, both landed and visible): S^T = K Q^T,
+// online softmax on raw scores, O^T += V^T P^T -- the body of attn_core's loop without the ring (short key sets: the 77 text
+// + T image tokens of the cross-attention layers are staged once, ahead of the fused kernel's projection).
+template <typename T>
+__device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
+                                          const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
+                                          float& m_run, float& l_run) {
+    typedef typename Vec<T>::v8 v8;
+    const int hi = lane >> 5;
+    const bool ragged = kbase + ATT_KV > Lk;
+    f32x16 st[2];
+    {
+        v8 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) kf[kt][sd] = *(const v8*)(ks + att_k_off(lane, kt, sd));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) st[kt] = mfma32(kf[kt][sd], qf[sd], st[kt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    v8 vf[2][2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) vf[kt][s][dt] = *(const v8*)(vs + att_v_off(lane, dt, kt, s));
+    __builtin_amdgcn_sched_barrier(0);
+    if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
+    }
+    float mx = max3f(st[0][0], st[1][0], st[0][1]);
+    mx = max3f(mx, st[1][1], st[0][2]);
+#pragma unroll
+    for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
+    mx = fmaxf(mx, st[1][15]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const f32x2 c2 = {c, c};
+    const f32x2 nmc2 = {-m_new * c, -m_new * c};
+    f32x2 ps2 = {0.f, 0.f};
+    v8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 s2 = {st[kt][r], st[kt][r + 1]};
+            const f32x2 e2 = __builtin_elementwise_fma(s2, c2, nmc2);
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+            ps2 += p2;
+            pf[kt][r >> 3][r & 7] = from_f32<T>(p2[0]);
+            pf[kt][r >> 3][(r & 7) + 1] = from_f32<T>(p2[1]);
+        }
+    if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        m_run = m_new;
+    }
+    l_run += ps2[0] + ps2[1];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s][dt], pf[kt][s], o[dt]);
+}
+
+// LDS-DMA of one 64-key K / V^T tile pair by the four waves of a head group (wave = 0..3 inside the group): the staging map
+// of attn_core's ring (rows of 8 per wave instruction, source-side swizzle)
+template <typename T>
+__device__ __forceinline__ void attn_stage_tile(const T* Kp, const T* Vp, const int Lkp, const int ldk, const int ldvt, const int b,
+                                                const int h, const int tile, unsigned char* ks, unsigned char* vs, const int wave,
+                                                const int lane) {
+    const int kbase = tile * ATT_KV;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + wave * 8 + (lane >> 3);
+        const int ch = stage_chunk_x(row, lane);
+        glds16(Kp + ((size_t)b * Lkp + kbase + row) * ldk + h * 64 + ch * 8, ks + (i * 32 + wave * 8) * 128);
+        glds16(Vp + ((size_t)h * 64 + row) * ldvt + (size_t)b * Lkp + kbase + ch * 8, vs + (i * 32 + wave * 8) * 128);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined key loop (self-attention, one key set).  attn_core above runs  QK^T(t) -> softmax(t) -> PV(t)  strictly in
+// order inside a wave: the matrix pipe idles during the softmax (32 v_exp_f32 + ~90 VALU per tile: as long as all 16 MFMAs
+// of the tile) and the VALU idles during the MFMAs; a single wave needs ~2100 cycles per 64-key tile for 512 cycles of MFMA
+// work (tools/attn_phase_probe.py).  Here the two halves of consecutive tiles overlap inside ONE instruction stream:
+//     phase B(t):  S(t+1) = K(t+1) Q^T   (8 MFMAs)   beside   P(t) = exp2(S(t) c - m c), row sums, packing     (VALU)
+//     phase A(t):  O^T += V^T(t) P(t)^T  (8 MFMAs)   beside   row max of S(t+1), new running max               (VALU)
+// (MFMAs issue in a few cycles and execute for 32; the VALU work is placed in their shadow with sched_group_barrier, the
+// recipe of cdna_hip_programming.md "Fused attention prefill" for one wave per SIMD.)  The running-max rescale of O is a
+// wave-uniform branch taken only when some row maximum moved.  K / V^T tiles come from a 4-slot LDS-DMA ring with counted
+// vmcnt: at the top of iteration t tile t+1 must have landed (its K feeds phase B, V(t) landed one iteration earlier), tiles
+// t+2 and t+3 stay in flight; one s_barrier per tile.
+constexpr int ATT_PIPE_STAGES = 4;
+
+template <typename T>
+__device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned char* smem, const typename Vec<T>::v8 (&qf)[4],
+                                               const int b, const int h, const int wave, const int lane, f32x16 (&fin)[2]) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int S = ATT_PIPE_STAGES, LPT = 4;
+    const int hi = lane >> 5;
+    const float c = p.scale * LOG2E;
+    const T* Kp = (const T*)p.K;
+    const T* Vp = (const T*)p.Vt;
+    const int Lk = p.Lk;
+    const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+    auto stage = [&](int tile) {
+        unsigned char* ks = smem + (tile & (S - 1)) * 2 * ATT_TILE_BYTES;
+        attn_stage_tile<T>(Kp, Vp, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, ks, ks + ATT_TILE_BYTES, wave, lane);
+    };
+    // the same tile in four single-instruction pieces (q = 2 * round + (0: K, 1: V^T))
+    const int srow = wave * 8 + (lane >> 3);
+    auto stage_piece = [&](int tile, int q) {
+        unsigned char* ks = smem + (tile & (S - 1)) * 2 * ATT_TILE_BYTES;
+        const int i = q >> 1;
+        const int row = i * 32 + srow;
+        const int ch = stage_chunk_x(row, lane);
+        const int kbase = tile * ATT_KV;
+        if (q & 1) glds16(Vp + ((size_t)h * 64 + row) * p.ldvt + (size_t)b * p.Lk_pad + kbase + ch * 8, ks + ATT_TILE_BYTES + (i * 32 + wave * 8) * 128);
+        else glds16(Kp + ((size_t)b * p.Lk_pad + kbase + row) * p.ldk + h * 64 + ch * 8, ks + (i * 32 + wave * 8) * 128);
+    };
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // raw scores of one tile: 8 K fragments, 8 MFMAs
+    auto qk = [&](f32x16 (&st)[2], const unsigned char* ks) {
+        v8 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) kf[kt][sd] = *(const v8*)(ks + att_k_off(lane, kt, sd));
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) st[kt] = mfma32(kf[kt][sd], qf[sd], st[kt]);
+        }
+    };
+    // row maximum (lane-local row, one cross-half exchange)
+    auto rowmax = [&](f32x16 (&st)[2], const int tile) -> float {
+        (void)tile; (void)hi;
+        float mx = max3f(st[0][0], st[1][0], st[0][1]);
+        mx = max3f(mx, st[1][1], st[0][2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
+        mx = fmaxf(mx, st[1][15]);
+        return xhalf_max(mx);
+    };
+    auto rescale = [&](const float m_new) {
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < ntiles) stage(s);
+    if (ntiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ntiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // tile 0 has landed for every wave
+    asm volatile("" ::: "memory");
+    f32x16 stA[2], stB[2];
+    qk(stA, smem);
+    rescale(fmaxf(m_run, rowmax(stA, 0)));
+
+    // one iteration: softmax + PV of tile t (raw scores in `cur`), QK^T of tile t + 1 (into `nxt`).  The interleave is written
+    // out by hand and pinned with sched_barrier(0) fences (sched_group_barrier patterns were not honoured at this register
+    // pressure): one MFMA, then the slice of VALU work that issues in its shadow.
+    auto iter = [&](auto HN, auto STG, f32x16 (&cur)[2], f32x16 (&nxt)[2], const int t) {
+        // has_next and the staging mode (0 none, 1 always, 2 runtime check) are compile-time: with runtime flags hipcc moved the
+        // eight MFMAs of phase B into one block and the softmax slices into another (no overlap at all).  No masking code either:
+        // the launcher takes this kernel only for key counts that are multiples of 64 (every SDXL self-attention)
+        constexpr bool has_next = decltype(HN)::value;
+        constexpr int stg = decltype(STG)::value;
+        const bool stage_more = stg == 1 || (stg == 2 && has_next && t + 3 < ntiles);   // tile t + 3 -> the slot of tile t - 1
+        if (has_next) {
+            if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");   // tile t + 1 landed, t + 2 in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // ... for every wave; every wave is past its reads of tile t - 1
+            asm volatile("" ::: "memory");
+        }
+        const unsigned char* vs = smem + (t & (S - 1)) * 2 * ATT_TILE_BYTES + ATT_TILE_BYTES;
+        const unsigned char* ksn = smem + ((t + 1) & (S - 1)) * 2 * ATT_TILE_BYTES;
+        v8 kf[2][4], vf[2][2][2];
+        if (has_next) {
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) kf[kt][sd] = *(const v8*)(ksn + att_k_off(lane, kt, sd));
+        }
+        auto v_reads = [&]() {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) vf[kt][s2][dt] = *(const v8*)(vs + att_v_off(lane, dt, kt, s2));
+        };
+        if (!has_next) v_reads();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: S(t+1) MFMAs beside P(t) ----
+        const f32x2 c2 = {c, c};
+        const f32x2 nmc2 = {-m_run * c, -m_run * c};
+        f32x2 ps2 = {0.f, 0.f};
+        v8 pf[2][2];
+        auto p_chunk = [&](auto J) {                   // 4 of the tile's 32 scores per lane: 2 pk_fma, 4 exp, 2 pk_add, 2 cvt_pk
+            constexpr int j = decltype(J)::value;
+            constexpr int kt = j >> 2, r0 = (j & 3) * 4;
+#pragma unroll
+            for (int r = r0; r < r0 + 4; r += 2) {
+                const f32x2 s2 = {cur[kt][r], cur[kt][r + 1]};
+                const f32x2 e2 = __builtin_elementwise_fma(s2, c2, nmc2);
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                ps2 += p2;
+                pf[kt][r >> 3][r & 7] = from_f32<T>(p2[0]);
+                pf[kt][r >> 3][(r & 7) + 1] = from_f32<T>(p2[1]);
+            }
+        };
+        auto b_step = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int sd = j >> 1, kt = j & 1;      // alternate the two accumulators: no back-to-back dependent MFMAs
+            p_chunk(J);                                 // the slice first: the K fragment reads above land under slice 0
+            if constexpr (j == 3) { if (has_next) v_reads(); }     // V^T fragments are for phase A: requested mid-way
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                if constexpr (sd == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) nxt[kt][r] = 0.f;
+                }
+                nxt[kt] = mfma32(kf[kt][sd], qf[sd], nxt[kt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        b_step(std::integral_constant<int, 0>{}); b_step(std::integral_constant<int, 1>{});
+        b_step(std::integral_constant<int, 2>{}); b_step(std::integral_constant<int, 3>{});
+        b_step(std::integral_constant<int, 4>{}); b_step(std::integral_constant<int, 5>{});
+        b_step(std::integral_constant<int, 6>{}); b_step(std::integral_constant<int, 7>{});
+        l_run += ps2[0] + ps2[1];
+        // ---- phase A: PV(t) MFMAs beside the row maximum of S(t+1) ----
+        float mx = NEG_BIG;
+        __builtin_amdgcn_sched_barrier(0);
+        auto a_step = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int kt = j >> 2, s2 = (j >> 1) & 1, dt = j & 1;
+            o[dt] = mfma32(vf[kt][s2][dt], pf[kt][s2], o[dt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {                             // 32 scores in 8 slices of 4: two v_max3 each
+                constexpr int k2 = j >> 2, r0 = (j & 3) * 4;
+                mx = max3f(mx, nxt[k2][r0], nxt[k2][r0 + 1]);
+                mx = max3f(mx, nxt[k2][r0 + 2], nxt[k2][r0 + 3]);
+                if constexpr (j >= 2 && j < 6 && stg != 0) {     // ... and one of the four LDS-DMA pieces of tile t + 3
+                    if (stage_more) stage_piece(t + 3, j - 2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        a_step(std::integral_constant<int, 0>{}); a_step(std::integral_constant<int, 1>{});
+        a_step(std::integral_constant<int, 2>{}); a_step(std::integral_constant<int, 3>{});
+        a_step(std::integral_constant<int, 4>{}); a_step(std::integral_constant<int, 5>{});
+        a_step(std::integral_constant<int, 6>{}); a_step(std::integral_constant<int, 7>{});
+        if (has_next) rescale(fmaxf(m_run, xhalf_max(mx)));
+        asm volatile("" ::: "memory");
+    };
+    const std::integral_constant<bool, true> YES{};
+    const std::integral_constant<bool, false> NO{};
+    const std::integral_constant<int, 0> STG_NONE{};
+    const std::integral_constant<int, 1> STG_ALWAYS{};
+    const std::integral_constant<int, 2> STG_CHECK{};
+    int t = 0;
+    for (; t + 4 < ntiles; t += 2) {              // steady state: tiles t + 3 and t + 4 exist
+        iter(YES, STG_ALWAYS, stA, stB, t);
+        iter(YES, STG_ALWAYS, stB, stA, t + 1);
+    }
+    for (; t + 2 < ntiles; t += 2) {              // the last few tiles: staging by runtime check
+        iter(YES, STG_CHECK, stA, stB, t);
+        iter(YES, STG_CHECK, stB, stA, t + 1);
+    }
+    if (t + 1 < ntiles) {
+        iter(YES, STG_NONE, stA, stB, t);
+        iter(NO, STG_NONE, stB, stA, t + 1);
+    } else {
+        iter(NO, STG_NONE, stA, stB, t);
+    }
+
+    __builtin_amdgcn_s_barrier();          // nobody reads the ring any more (the caller reuses it for the O staging rows)
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[dt][r] = o[dt][r] * inv;
 }
 
 // O tile through the wave's private staging rows of smem (rows wave*32 ..): lane (q, hi) owns d = dt*32 + 8*rg + 4*hi + e,

@@ -29,7 +29,8 @@
 namespace imh {
 
 int g_xattn_mode = 0;   // imh_debug_set key 3: 0 auto (two heads per workgroup when H is even), 1 one head per workgroup (round-2 kernel),
-                        // 2 two heads, eight do-everything waves, 3 two heads + two producer waves, 4 two heads + four producer waves
+                        // 2 two heads, eight do-everything waves, 3 two heads + two producer waves, 4 two heads + four producer waves;
+                        // 6 / 7 / 8 = 2 / 3 / 4 without the resident key tiles
 
 
 constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
@@ -176,7 +177,11 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 // (s_barrier waits on surviving waves only).
 constexpr int XQ2_STAGE = 128 * 128 + 128 * 128;   // X tile (128 token rows) + Wq tile (2 heads x 64 dims), 128 B per row
 
-template <typename T, int NPASS, int LNQ, int NP, int S>
+// RES: the key sets are short (<= 2 text tiles, <= 1 image-prompt tile -- every SDXL cross-attention layer): the text K / V^T
+// tiles of both heads are staged ONCE into a dedicated 64 KB of LDS by the consumer waves at kernel entry (in flight under
+// the whole projection), the image-prompt tile right after the projection (in flight under the text pass); the key loop then
+// runs from resident tiles without a single load wait.  (The ring form below pays two dependent L2 round trips per pass.)
+template <typename T, int NPASS, int LNQ, int NP, int S, bool RES>
 __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnParams xp) {
     typedef typename Vec<T>::v8 v8;
     constexpr int NI = 32;                              // LDS-DMA wave instructions per K tile (8 rows x 128 B each)
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     constexpr int LP = NI / NISS;
     constexpr int GROUP_BYTES = ATT_STAGES * 2 * ATT_TILE_BYTES;      // one head group's K / V^T ring (+ Q / O staging rows)
     static_assert(S * XQ2_STAGE >= 2 * GROUP_BYTES, "the projection ring covers both key-loop rings");
+    static_assert(!RES || S * XQ2_STAGE + 2 * 4 * ATT_TILE_BYTES <= 160 * 1024, "ring + resident text tiles fit the LDS");
     static_assert((S - 2) * LP <= 63 && NI % NISS == 0, "vmcnt range / even split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttnParams& p = xp.a;
@@ -242,6 +248,13 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     // ---------------------------------------------------------------------- consumer
     const int g = wave >> 2, qg = wave & 3;
     const int h = h0 + g;
+    unsigned char* const res = smem + S * XQ2_STAGE + g * (4 * ATT_TILE_BYTES);     // RES: this head's two text K / V^T tile pairs
+    const int nt1 = (p.Lk + ATT_KV - 1) / ATT_KV;
+    if constexpr (RES) {
+        for (int t = 0; t < nt1; ++t)
+            attn_stage_tile<T>((const T*)p.K, (const T*)p.Vt, p.Lk_pad, p.ldk, p.ldvt, b, h, t, res + t * 2 * ATT_TILE_BYTES,
+                               res + t * 2 * ATT_TILE_BYTES + ATT_TILE_BYTES, qg, lane);
+    }
     int xoff[4], woff[2][4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
             for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
         }
         if constexpr (NP > 0) {
+            if (RES && kt == nkt - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's resident text tiles landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tile kt has been read: its slot may be refilled
             __builtin_amdgcn_s_barrier();                            // ... and tile kt + 1 has landed
         }
@@ -351,35 +365,84 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
 
     unsigned char* gs = smem + g * GROUP_BYTES;
     f32x16 fin[2];
-    attn_core<T, 4, NPASS>(p, gs, qf, b, h, qg, lane, item, fin);
+    if constexpr (RES) {
+        const float c = p.scale * LOG2E;
+        if constexpr (NPASS == 2)      // the image-prompt tile: into the (dead) projection ring, in flight under the text pass
+            attn_stage_tile<T>((const T*)p.K2, (const T*)p.Vt2, p.Lk2_pad, p.ldk2, p.ldvt2, b, h, 0, gs, gs + ATT_TILE_BYTES, qg, lane);
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = NEG_BIG, l_run = 0.f;
+        // the text tiles were issued before the projection by this group's own waves: every wave's vmcnt(0) before the last
+        // projection barrier (NP == 0) or right here (NP > 0: consumers issue nothing else) + that barrier make them visible
+        for (int t = 0; t < nt1; ++t)
+            attn_tile<T>(res + t * 2 * ATT_TILE_BYTES, res + t * 2 * ATT_TILE_BYTES + ATT_TILE_BYTES, qf, lane, t * ATT_KV, p.Lk, c, o, m_run, l_run);
+        {
+            const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fin[dt][r] = o[dt][r] * inv;
+        }
+        if constexpr (NPASS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's part of the image-prompt tile has landed
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+            m_run = NEG_BIG; l_run = 0.f;
+            attn_tile<T>(gs, gs + ATT_TILE_BYTES, qf, lane, 0, p.Lk2, c, o, m_run, l_run);
+            const float wgt = p.scale2_tab ? p.scale2_tab[*p.step] : p.scale2;
+            const float inv = wgt / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fin[dt][r] += o[dt][r] * inv;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // the group is done reading the tile: its rows become O staging rows
+        }
+    } else {
+        attn_core<T, 4, NPASS>(p, gs, qf, b, h, qg, lane, item, fin);
+    }
     attn_store<T, 4>(p, gs, fin, b, h, q0, qg, lane);
     if (NP == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 512);
 }
 
-template <typename T, int NPASS, int LNQ, int NP, int S>
+template <typename T, int NPASS, int LNQ, int NP, int S, bool RES>
 static void launch_xattn2(const XAttnParams& xp, hipStream_t stream) {
     const AttnParams& p = xp.a;
     const int items = ((p.Lq + 127) / 128) * (p.H / 2) * p.B;
     dim3 grid(8 * ((items + 7) / 8));
-    const int lds = S * XQ2_STAGE;
-    auto kern = xattn2_kernel<T, NPASS, LNQ, NP, S>;
+    const int lds = S * XQ2_STAGE + (RES ? 2 * 4 * ATT_TILE_BYTES : 0);
+    auto kern = xattn2_kernel<T, NPASS, LNQ, NP, S, RES>;
     static DynLdsOnce once;
     once.ensure((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + NP)), lds, stream, xp);
 }
 
-template <typename T, int NP, int S>
-static void launch_xattn2_np(const XAttnParams& xp, hipStream_t stream) {
+template <typename T, int NP, int S, bool RES>
+static void launch_xattn2_res(const XAttnParams& xp, hipStream_t stream) {
     const int lnq = !xp.ln_s ? 0 : (xp.ln_stats ? 2 : 1);
     if (xp.a.K2) {
-        if (lnq == 0) launch_xattn2<T, 2, 0, NP, S>(xp, stream);
-        else if (lnq == 1) launch_xattn2<T, 2, 1, NP, S>(xp, stream);
-        else launch_xattn2<T, 2, 2, NP, S>(xp, stream);
+        if (lnq == 0) launch_xattn2<T, 2, 0, NP, S, RES>(xp, stream);
+        else if (lnq == 1) launch_xattn2<T, 2, 1, NP, S, RES>(xp, stream);
+        else launch_xattn2<T, 2, 2, NP, S, RES>(xp, stream);
     } else {
-        if (lnq == 0) launch_xattn2<T, 1, 0, NP, S>(xp, stream);
-        else if (lnq == 1) launch_xattn2<T, 1, 1, NP, S>(xp, stream);
-        else launch_xattn2<T, 1, 2, NP, S>(xp, stream);
+        if (lnq == 0) launch_xattn2<T, 1, 0, NP, S, RES>(xp, stream);
+        else if (lnq == 1) launch_xattn2<T, 1, 1, NP, S, RES>(xp, stream);
+        else launch_xattn2<T, 1, 2, NP, S, RES>(xp, stream);
     }
+}
+
+// res: short key sets (see RES above) -> 3-stage projection ring + resident text tiles; else the 4-stage ring + key-loop rings
+template <typename T, int NP>
+static void launch_xattn2_np(const XAttnParams& xp, hipStream_t stream, bool res) {
+    if (res) launch_xattn2_res<T, NP, 3, true>(xp, stream);
+    else launch_xattn2_res<T, NP, 4, false>(xp, stream);
 }
 
 int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
@@ -414,15 +477,14 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
         else IMH_XA(f16_t);
 #undef IMH_XA
 #undef IMH_XA1
-    } else if (mode == 2) {
-        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 0, 4>(xp, stream);
-        else launch_xattn2_np<f16_t, 0, 4>(xp, stream);
-    } else if (mode == 4) {
-        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 4, 4>(xp, stream);
-        else launch_xattn2_np<f16_t, 4, 4>(xp, stream);
     } else {
-        if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 2, 4>(xp, stream);
-        else launch_xattn2_np<f16_t, 2, 4>(xp, stream);
+        // modes 2 / 3 / 4: two heads per workgroup with 0 / 2 / 4 producer waves; +4 (6 / 7 / 8): the same without the resident
+        // key tiles (A/B)
+        const bool res = mode < 6 && p.Lk <= 2 * ATT_KV && (!p.K2 || p.Lk2 <= ATT_KV);
+        const int m = mode >= 6 ? mode - 4 : mode;
+        if (m == 2) { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 0>(xp, stream, res); else launch_xattn2_np<f16_t, 0>(xp, stream, res); }
+        else if (m == 4) { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 4>(xp, stream, res); else launch_xattn2_np<f16_t, 4>(xp, stream, res); }
+        else { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 2>(xp, stream, res); else launch_xattn2_np<f16_t, 2>(xp, stream, res); }
     }
     return check_launch("xattn_kernel");
 }

@@ -214,8 +214,20 @@ def sdpa_ref(q, k, v, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192)])
-def test_attention_self(L, dtype, B, H, Lq):
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192), (1, 3, 128), (2, 1, 320), (1, 2, 384), (1, 1, 448),
+                                    (1, 1, 512), (1, 2, 4096)])
+def test_attention_self(L, dtype, mode, B, H, Lq):
+    """mode (imh_debug_set key 4): 1 = in-order key loop, 2 = software-pipelined key loop (every tail of its unrolled tile
+    loop: 1 .. 8, 16, 64 tiles; a key count that is not a multiple of 64 always takes the in-order kernel)"""
+    assert L.load().imh_debug_set(4, mode) == 0
+    try:
+        _attention_self_case(L, dtype, B, H, Lq)
+    finally:
+        L.load().imh_debug_set(4, 0)
+
+
+def _attention_self_case(L, dtype, B, H, Lq):
     ctx = ctx_for(dtype)
     C_ = H * 64
     qk = rnd(B * Lq, 2 * C_, dtype=dtype, seed=1)
@@ -309,8 +321,17 @@ def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_st
     assert_close(out.view(B, Lq, C_), ref, dtype, f"fused cross attention B={B} H={H} Lq={Lq} nt={nt} nip={nip} ln={ln}", k=8.0)
 
 
-def test_attention_spiked_scores(L):
-    """forces the online-softmax rescale path: one key dominates late in the sequence"""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_spiked_scores(L, mode):
+    """forces the online-softmax rescale path: one key dominates late in the sequence (both key loops)"""
+    assert L.load().imh_debug_set(4, mode) == 0
+    try:
+        _spiked_case(L)
+    finally:
+        L.load().imh_debug_set(4, 0)
+
+
+def _spiked_case(L):
     dtype = torch.bfloat16
     ctx = ctx_for(dtype)
     B, H, Lq = 1, 1, 256
