@@ -17,6 +17,8 @@ Two entry points per processor:
                      text / image-prompt K,V taken from a per-image cache (they do not depend on the
                      denoise step; the reference recomputes them 30x).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,7 @@ from . import lib as L
 from .ctx import Ctx
 
 HEAD_DIM = 64
+DUAL_WS = os.environ.get("IMH_DUAL_WS", "1") != "0"     # A/B: the wave-specialised projection pair of self-attention
 
 
 def _pad64(n):
@@ -154,8 +157,10 @@ class AttnProcessor2_0(nn.Module):
                 fold_ln(attn.to_v.weight, norm, ctx)))
             g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps, ln_stats))
             g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], norm.eps, ln_stats))
-        # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch
-        qk, vt = ctx.gemm_dual(g1, g2, descr="self.to_qk+v^T")
+        # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch -- with handed-over LayerNorm statistics
+        # the wave-specialised pair (variant 24128: 128 x 160 + 128 x 128 tiles), else the two-stage 128-row tiles
+        ws = ln is not None and ln_stats is not None and DUAL_WS and (B * L_) % 128 == 0 and C_ % 160 == 0
+        qk, vt = ctx.gemm_dual(g1, g2, cfg=(24128, 160) if ws else (128, 64), descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")

@@ -48,7 +48,7 @@ static int do_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, hipStrea
     if (!a || !b || !a->X || !a->W || !a->Y || !b->X || !b->W || !b->Y) { set_error("gemm_dual: null pointer argument"); return IMH_ERR_ARG; }
     if (a->conv || b->conv || a->dtype != b->dtype) { set_error("gemm_dual: both problems must be plain GEMMs of one dtype"); return IMH_ERR_ARG; }
     int bm = a->bm, bn = a->bn;
-    if (bm <= 0 || bn <= 0 || bm > 128) { bm = 128; bn = 64; }
+    if (bm != 24128 && (bm <= 0 || bn <= 0 || bm > 128)) { bm = 128; bn = 64; }
     for (const imh_gemm_args* g : {a, b}) {
         if ((g->flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!g->ln_s || !g->ln_c || !(g->ln_eps > 0.f))) {
             set_error("gemm_dual: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG;

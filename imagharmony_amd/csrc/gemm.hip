@@ -363,6 +363,7 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
 }
 
 int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream);
+int gemm_ws_dual_launch(const GemmParams& a, const GemmParams& b, int dtype, hipStream_t stream);   // gemm_ring.hip: variant code 24128
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream);       // conv_halo.hip: variant codes 7128 / 7564 x 320 / 160
 int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t stream);      // gemm_pp.hip: variant codes 8256 x 256, 9128 x 320
 
@@ -443,6 +444,15 @@ int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipS
     if (((a.flags | b.flags) & lnf) && !((a.flags & lnf) == GF_LN_ROW && (b.flags & lnf) == GF_LN_COL)) {
         set_error("gemm_dual: folded LayerNorm needs problem a in row form and problem b in column form");
         return IMH_ERR_ARG;
+    }
+    if (bm == 24128) {       // wave-specialised pair: [Q|K] row form on 128 x 160 tiles + V^T column form on 128 x 128 tiles
+        if (!a.ln_stats || !b.ln_stats || (a.flags & ~GF_LN_ROW) != 0 || !(a.flags & GF_LN_ROW) ||
+            (b.flags & ~(GF_LN_COL | GF_VT_PERM)) != 0 || !(b.flags & GF_LN_COL)) {
+            set_error("gemm_dual: variant 24128 is the self-attention projection pair with handed-over LayerNorm statistics "
+                      "(a: IMH_GF_LN_ROW, b: IMH_GF_LN_COL [| IMH_GF_VT_PERM], ln_stats on both)");
+            return IMH_ERR_ARG;
+        }
+        return gemm_ws_dual_launch(a, b, dtype, stream);
     }
     if (((a.flags | b.flags) & GF_VT_PERM) && bn != 128) bn = 128;     // the permutation lives in 16-column groups
     if (dtype == IMH_DT_BF16) return launch_dual_typed<bf16_t>(a, b, bm, bn, stream);

@@ -418,11 +418,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // consumers through a dead ring slot with the last hand-over.  (Summing in the loader waves themselves put ~600 cycles
 // per K tile on the loaders' critical path: +8..10 us on the ff.net.0 launch.)
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
-__global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid, const int nblocks, unsigned char* smem) {
     constexpr int NC = CM * CN;
     constexpr int TM = BM / CM, TN = BN / CN;
     static_assert(LN != 1 || (!CONV && NP >= 3), "LN = 1: two loader waves + NP - 2 statistics waves");
-    static_assert(LN != 2 || !CONV, "folded LayerNorm is a Linear-layer form");
+    static_assert((LN != 2 && LN != 3) || !CONV, "folded LayerNorm is a Linear-layer form");
     constexpr int NL = LN == 1 ? 2 : NP;           // loader waves; with in-loop LN the other producers only sum rows
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
@@ -434,14 +434,13 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
     static_assert((S - 2) * LP <= 63, "vmcnt range");
     static_assert(TN % (4 * FN) == 0, "weight fragment rows");
     typedef typename Vec<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int m0, n0;
-    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;     // the whole workgroup exits together
+    if (!xcd_tile<BM, BN>(p, bid, m0, n0)) return;     // the whole workgroup exits together
     const int nkt = p.K / GEMM_BK;
     const int z = blockIdx.y;
     const int per = (nkt + p.splits - 1) / p.splits;
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             __builtin_amdgcn_s_barrier();
             if (++slot == S) slot = 0;
         }
-        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 64 * NC, 64 * NL);
+        if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, nblocks, tid - 64 * NC, 64 * NL);
         return;
     }
 
@@ -643,6 +642,16 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if constexpr (LN == 3) {                       // column form (tokens = the W operand's rows = output columns): the tile's BN tokens
+        const int t = wave * 64 + lane;
+        if (t < BN) {
+            const int n = n0 + t;
+            f32x2s mr = {0.f, 1.f};
+            if (n < p.N) mr = merge_row_stats(p.ln_stats, n, p.ln_slots, p.K, p.ln_eps);
+            *(f32x2s*)(smem + S * STAGE + t * 8) = mr;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                  // tile 0 has landed
     asm volatile("" ::: "memory");
     int slot = 0;
@@ -673,7 +682,15 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
     if (pre.ok && p.bias) ldv<T, 4 * FN>((const T*)p.bias + nb, pre.bias);
     LnArgs<4 * FN> ln;
     float st_s[FM], st_q[FM];
-    if constexpr (LN != 0) {                       // mean / rstd of the tile's rows: published by the statistics waves (LN = 1, see
+    if constexpr (LN == 3) {
+        const f32x2s* ex = (const f32x2s*)(smem + S * STAGE);
+#pragma unroll
+        for (int q = 0; q < 4 * FN; ++q) {
+            const f32x2s mr = ex[wn * TN + (lane >> 4) * 4 * FN + q];
+            ln.cm[q] = mr[0]; ln.cr[q] = mr[1];
+        }
+    }
+    if constexpr (LN == 1 || LN == 2) {            // mean / rstd of the tile's rows: published by the statistics waves (LN = 1, see
         // above) or merged from the producer kernel's partials before the loop (LN = 2)
         const float* ex = (const float*)(smem + (LN == 2 ? S : ((nt + S - 2) % S)) * STAGE);
 #pragma unroll
@@ -683,7 +700,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
             st_q[i] = ex[r * 2 + 1];
         }
     }
-    if constexpr (LN != 0) {
+    if constexpr (LN == 1 || LN == 2) {
         // the transformer blocks' launches (ff.net.0: LN + bias + GEGLU; to_q / to_k: LN only) take a lean epilogue: whole
         // 4*FN-column run in range, vector-aligned output, no row-add / residual / activation -- operands fetched once
         // above, then per row the LN formula, the GEGLU product and ONE store
@@ -772,10 +789,48 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const G
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            if constexpr (LN != 0) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
+            if constexpr (LN == 1 || LN == 2) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
             epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane);
         }
     }
+}
+
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
+__global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_ws_body<T, BM, BN, CM, CN, S, NP, CONV, LN>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Self-attention's projections in ONE wave-specialised launch, LayerNorm statistics handed over (imh_lnstats.h):
+//   a: [Q|K] = LN(x) [Wq;Wk]^T   row form, 128 x 160 tiles (M = 2048 x N = 2560 -> 256 tiles)
+//   b: V^T   = Wv LN(x)^T        column form + V^T key permutation, 128 x 128 tiles (1280 x 2048 -> 160 tiles)
+// workgroups [0, grid_a) run a, the rest b (same 4 consumer + 4 producer waves, 4-stage rings).
+template <typename T>
+__global__ __launch_bounds__(512, 1) void gemm_ws_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x < grid_a) gemm_ws_body<T, 128, 160, 2, 2, 4, 4, false, 2>(a, blockIdx.x, gridDim.x, smem);
+    else gemm_ws_body<T, 128, 128, 2, 2, 4, 4, false, 3>(b, blockIdx.x - grid_a, gridDim.x, smem);
+}
+
+template <typename T>
+static int launch_ws_dual(const GemmParams& a, const GemmParams& b, hipStream_t stream) {
+    GemmParams qa = a, qb = b;
+    int ga, gb;
+    xcd_partition(qa, 128, 160, &ga);
+    xcd_partition(qb, 128, 128, &gb);
+    const size_t smem = 4 * (size_t)(128 + 160) * GEMM_ROW_BYTES + 128 * 8;
+    auto kern = gemm_ws_dual_kernel<T>;
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(ga + gb), dim3(512), smem, stream, qa, qb, ga);
+    return check_launch("gemm_ws_dual_kernel");
+}
+
+int gemm_ws_dual_launch(const GemmParams& a, const GemmParams& b, int dtype, hipStream_t stream) {
+    if (dtype == IMH_DT_BF16) return launch_ws_dual<bf16_t>(a, b, stream);
+    if (dtype == IMH_DT_F16) return launch_ws_dual<f16_t>(a, b, stream);
+    set_error("gemm_ws_dual: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
 }
 
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
@@ -783,7 +838,7 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
-    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 2 ? BM * 8 : 0);
+    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 2 ? BM * 8 : (LN == 3 ? BN * 8 : 0));
     auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);

@@ -12,7 +12,7 @@
 namespace imh {
 
 constexpr int GN_THREADS = 512;
-constexpr int GN_ELEMS_PER_BLOCK = 32768;
+constexpr int GN_ELEMS_PER_BLOCK = 8192;     // 32768 left the 32 x 32 levels (1.3 M elements per sample) on 80 workgroups of 256 CUs
 
 static inline int gn_nblk(int HW, int C) {
     long long e = (long long)HW * C;

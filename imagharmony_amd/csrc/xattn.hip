@@ -462,8 +462,11 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     }
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("cross_attention: empty problem"); return IMH_ERR_SHAPE; }
     if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("cross_attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    // auto = one head per workgroup: in the forward (operands cold in this XCD's L2) its 320 workgroups on all 256 CUs pull the
+    // token rows and weights faster than the 160 workgroups of the two-head form, which only wins back-to-back on warm
+    // operands (profiles/r03_attn_ab.json vs r03_forward_ab_*.json)
     int mode = g_xattn_mode;
-    if (mode == 0) mode = 3;
+    if (mode == 0) mode = 1;
     if ((p.H & 1) || mode == 1) {
         const int items = ((p.Lq + 127) / 128) * p.H * p.B;
         dim3 grid(8 * ((items + 7) / 8));

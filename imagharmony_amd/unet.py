@@ -40,6 +40,10 @@ FOLD_LAYERNORM = True
 # instead of every consumer re-deriving the statistics inside its K loop (64-fold redundant for ff.net.0: every column tile
 # of a row block repeated them).  False = in-loop statistics (A/B; IMH_LN_STATS=0 in the environment).
 LN_STATS_HANDOVER = os.environ.get("IMH_LN_STATS", "1") != "0"
+# ... except into the fused cross-attention kernel: its to_q prologue takes norm2's statistics from the MFMA operand fragments
+# it reads anyway, which measured faster in the forward than a dependent load chain at kernel entry (27.3 vs 28.4 us per
+# launch, profiles/r03_forward_ab_stats.json); so attn1's to_out leaves no statistics behind
+XATTN_STATS_HANDOVER = os.environ.get("IMH_XATTN_STATS", "0") != "0"
 
 
 @dataclass
@@ -227,8 +231,9 @@ class BasicTransformerBlock(nn.Module):
             ho = LN_STATS_HANDOVER
             if not ho:
                 stats = None
-            r = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1, ln_stats=stats, want_stats=ho)
-            h1, s1 = r if ho else (r, None)
+            hx = ho and XATTN_STATS_HANDOVER
+            r = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1, ln_stats=stats, want_stats=hx)
+            h1, s1 = r if hx else (r, None)
             ctx.free(h)
             if stats is not None:
                 ctx.free(stats[0])

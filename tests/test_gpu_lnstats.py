@@ -154,3 +154,30 @@ def test_large_common_offset_rows(L, dtype):
     assert torch.isfinite(y_old.float()).all()
     print(f"{dtype}: handed-over statistics max err {err:.3e}; in-loop statistics max err {(y_old.float() - ref).abs().max().item():.3e} "
           f"(result scale {ref.abs().max().item():.2f})")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wave_specialised_projection_pair(L, dtype):
+    """variant 24128 of imh_gemm_dual: [Q|K] (row form, 128 x 160 tiles) + V^T (column form + V^T key permutation, 128 x 128
+    tiles) in one wave-specialised launch with handed-over statistics -- the self-attention projections of the forward"""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    for (M, C_) in [(256, 320), (2048, 1280), (8192, 640), (384, 960)]:
+        x = (rnd(M, C_, dtype=dtype, seed=1) * 1.5 + 2.0).contiguous()
+        wqk = rnd(2 * C_, C_, dtype=torch.float32, seed=2, scale=C_ ** -0.5)
+        wv = rnd(C_, C_, dtype=torch.float32, seed=3, scale=C_ ** -0.5)
+        norm = _norm(C_)
+        xn = F.layer_norm(x.float().cpu(), (C_,), norm.weight, norm.bias, 1e-5)
+        fq, fv = fold_ln(wqk, norm, ctx), fold_ln(wv, norm, ctx)
+        for how in (80, "kernel"):
+            st = _stats_for(ctx, x, how)
+            qk, vt = ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5, st)),
+                                   dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5, st)), cfg=(24128, 160))
+            assert_close(qk, (xn @ wqk.cpu().t()).to(DEV), dtype, f"[Q|K] {(M, C_)} {how}", k=6.0)
+            assert_close(vt_unpermute(vt), (wv.cpu() @ xn.t()).to(DEV), dtype, f"V^T {(M, C_)} {how}", k=6.0)
+            qk2, vt2 = ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5, st)),
+                                     dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5, st)), cfg=(24128, 160))
+            assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    with pytest.raises(L.ImhError, match="24128"):
+        ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5)),
+                      dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5)), cfg=(24128, 160))

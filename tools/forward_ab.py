@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from imagharmony_amd import lib as L                                   # noqa: E402
 from imagharmony_amd import unet as U                                  # noqa: E402
+from imagharmony_amd import attention_processor as AP                 # noqa: E402
 from imagharmony_amd.ctx import _load_tuning                           # noqa: E402
 from tools.sweep import DEV, build_unet, record                        # noqa: E402
 
@@ -38,13 +39,20 @@ CONFIGS = collections.OrderedDict([
     ("x3_a2", dict(xattn=3, attn=2)),
     ("x4_a2", dict(xattn=4, attn=2)),
     ("x4_a2_lin640", dict(xattn=4, attn=2, tuning={"8192,640,640,0": [24128, 160, 1]})),
+    # session D: wave-specialised projection pair of self-attention (dual_ws), in-loop vs handed-over statistics for the
+    # fused cross-attention (xstats)
+    ("d_base", dict(xattn=1, attn=1, dual_ws=False, xstats=True)),
+    ("d_xloop", dict(xattn=1, attn=1, dual_ws=False, xstats=False)),
+    ("d_dualws", dict(xattn=1, attn=1, dual_ws=True, xstats=False)),
+    ("d_dualws_pipe", dict(xattn=1, attn=2, dual_ws=True, xstats=False)),
+    ("d_all_lin640", dict(xattn=1, attn=2, dual_ws=True, xstats=False, tuning={"8192,640,640,0": [24128, 160, 1]})),
 ])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--configs", default="x1_a1,x3_a1,x4_a1,x7_a1,x3_a2,x4_a2,x4_a2_lin640")
+    ap.add_argument("--configs", default="d_base,d_xloop,d_dualws,d_dualws_pipe,d_all_lin640")
     ap.add_argument("--stacked", type=int, default=1)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
@@ -57,6 +65,8 @@ def main():
     for n in names:
         c = CONFIGS[n]
         U.LN_STATS_HANDOVER = bool(c.get("ln_stats", True))
+        U.XATTN_STATS_HANDOVER = bool(c.get("xstats", False))
+        AP.DUAL_WS = bool(c.get("dual_ws", True))
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
         tun = dict(_load_tuning())
