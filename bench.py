@@ -185,6 +185,74 @@ def resampler_extra(device, dtype):
     return out
 
 
+# tile (rows of the token operand, rows of the weight operand) staged per K tile by each variant code (include/imh.h)
+_TILE = {1464: (64, None), 2464: (64, None), 24128: (128, None), 23256: (256, None), 9128: (128, 320), 9256: (256, 320), 8256: (256, 256),
+         5258: (256, 320), 5256: (256, 320), 6128: (128, 320), 6064: (64, 160), 7064: (64, 160), 256: (256, None),
+         3128: (128, 128), 3064: (64, 64), 4064: (64, None), 4128: (128, 64), 5064: (64, 64)}
+
+
+def lds_operand_bytes(shape, epi, esz=2):
+    """bytes a GEMM / conv launch moves over the L2 -> LDS path (LDS-DMA): every workgroup stages its token tile and its weight
+    tile once per 64-wide K tile -- tiles x (BM + BN) x K x 2 B; the LDS-halo conv stages the (PH + 2) x 18 pixel halo once per
+    64-channel chunk and the weight tile once per (chunk, tap).  This, not HBM bytes or FLOPs, is what the M = 2048 layers of
+    the forward are bound by."""
+    if shape is None or epi is None or "cfg" not in epi:
+        return 0.0
+    M, N, K, conv, geom = shape
+    bm, bn, sp = epi["cfg"]
+    if bm in (7128, 7564):
+        B, H, W, Cin, stride, up = geom
+        ph = 8 if bm == 7128 else 4
+        Ho, Wo = H << up, W << up
+        tiles = B * -(-Ho // ph) * -(-Wo // 16) * -(-N // bn)
+        return float(tiles) * (Cin // 64) * ((ph + 2) * 18 * 128 + 9 * bn * 128)
+    tm, tn = _TILE.get(bm, (bm, bn))
+    tn = tn or bn
+    return float(-(-M // tm)) * -(-N // tn) * (tm + tn) * K * esz
+
+
+def ip_attn_cfg4(device, dtype, reps=20):
+    """the north-star call at BASELINE.json configs[3] / SURVEY 8a 'cfg4' (UNet batch 8, 16 Resampler tokens): one
+    IPAttnProcessor2_0 call on an IP-active layer = fused [to_q + norm2 + text SDPA + image-prompt SDPA + axpy] launch + [to_out +
+    residual] launch, `reps` calls recorded into a plan and timed with HIP events on the launch stream"""
+    from imagharmony_amd import lib as L
+    from imagharmony_amd.attention_processor import IPAttnProcessor2_0, fold_ln
+    from imagharmony_amd.ctx import Ctx
+    from imagharmony_amd.unet import Attention, Norm
+    B, Lq, C_, T, H = 8, 1024, 1280, 16, 20
+    g = torch.Generator(device="cpu").manual_seed(11)
+    attn = Attention(C_, H, cross_attention_dim=2048)
+    proc = IPAttnProcessor2_0(C_, 2048, scale=1.0, num_tokens=T)
+    norm = Norm(C_, 1e-5)
+    with torch.no_grad():
+        for p in list(attn.parameters()) + list(proc.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (p.shape[-1] ** -0.5 if p.ndim > 1 else 0.02))
+        norm.weight.fill_(1.0); norm.bias.zero_()
+    attn, proc, norm = attn.to(device, dtype), proc.to(device, dtype), norm.to(device, dtype)
+    x = torch.randn(B * Lq, C_, generator=g).to(device, dtype)
+    ehs = torch.randn(B, 77 + T, 2048, generator=g).to(device, dtype)
+    pre = Ctx(device, dtype)
+    kv = proc.prepare_kv(pre, attn, ehs)
+    rec = Ctx(device, dtype, record=True)
+    for _ in range(reps):
+        y = proc.emit(rec, attn, x, B, Lq, residual=x, kv=kv, ln=norm)
+        rec.free(y)
+    fl = sum(t[3] for t in rec.tags) / reps
+    rec.run(); torch.cuda.synchronize(device)
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rec.run(); e1.record(); torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        best = us if best is None else min(best, us)
+    kv_fl = 2.0 * 2 * B * (77 + T) * 2048 * C_
+    return {"bound": "mfma", "achieved": fl / (best * 1e-6) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / (best * 1e-6) / 1e12 / 2500.0,
+            "avg_call_us": best, "algorithmic_gflop_per_call": fl / 1e9, "algorithmic_gflop_per_call_survey_8a": (fl + kv_fl) / 1e9,
+            "shape": f"UNet batch {B} (4 candidates x CFG), L = {Lq}, C = {C_}, {T} image tokens",
+            "note": f"{reps} back-to-back calls (warm operands), HIP events around the recorded plan; K/V projections of the conditioning "
+                    "are step-invariant and not in the timed call"}
+
+
 def _self_launch(n, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RCCL) ourselves through
     torch.distributed.run; rank 0's single JSON line goes to our stdout.  Returns the launcher's exit code."""
@@ -311,6 +379,8 @@ def main():
         g_fl = sum(t[3] for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
         g_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
         g_by = sum(t[4] for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM)
+        g_lds = sum(lds_operand_bytes(t[5], t[6]) for t in rec.tags if t[1] == L.OP_GEMM and t[5] is not None)
+        g_lds_ms = sum(m for t, m in zip(rec.tags, ms) if t[1] == L.OP_GEMM and t[5] is not None)
         n_g = sum(1 for t in rec.tags if t[1] == L.OP_GEMM)
         tot_fl = sum(t[3] for t in rec.tags)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
@@ -333,12 +403,11 @@ def main():
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
         try:
-            pj = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-            if not os.path.exists(pj):
-                pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")
+            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
+                                                                          "r01_pmc_hbm_traffic_final.json")) if os.path.exists(q))
             traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
             traffic_src = f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command with --denoise-steps 4)"
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         images = a.steps * world
         res = {
@@ -367,7 +436,14 @@ def main():
                                    "frac": a_fl / (a_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::attn_kernel (self-attention)",
                                    "launches_per_step": n_a, "avg_launch_us": a_ms / n_a * 1e3,
                                    "algorithmic_tflop_per_step": a_fl / 1e12,
-                                   "note": "head_dim 64: softmax VALU time adds to MFMA time on a SIMD (profiles/r01_pmc_sq_gemm_attn.md)"},
+                                   "note": "head_dim 64: per 64-key tile a wave issues 16 MFMAs (512 cycles of the matrix pipe) and ~120 VALU "
+                                           "instructions incl. 32 v_exp_f32 (~600 cycles of the VALU pipe, profiles/r03_valu_mfma_rate_microbench.csv)"},
+            # what actually bounds the M = 2048 / 8192 layers: operand bytes through the L2 -> LDS path (LDS-DMA), see lds_operand_bytes
+            "roofline_l2_lds": {"bound": "l2->lds", "achieved": g_lds / (g_lds_ms * 1e-3) / 1e12, "unit": "TB/s",
+                                "peak": 17.2, "frac": g_lds / (g_lds_ms * 1e-3) / 1e12 / 17.2,
+                                "bytes_per_step": g_lds, "kernel": "same GEMM / conv family (dual launches excluded)",
+                                "note": "peak = 32 B/clk/CU x 256 CUs x 2.1 GHz (each XCD's L2 feeds its 32 CUs 1024 B/clk); the wave-specialised "
+                                        "kernels measure 58-67 GB/s per CU on every tile shape (profiles/r03_l2_lds_rate_microbench.csv)"},
         }
         if ip_us:
             kv_fl = 2.0 * 2 * 2 * (77 + a.ip_tokens) * 2048 * 1280          # text + ip K,V projections of one IP-active layer (CFG batch 2)
@@ -388,6 +464,11 @@ def main():
                 "bound": "mfma", "achieved": x_fl / (x_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": x_fl / (x_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::xattn_kernel (all 70 cross-attention layers: to_q + SDPA fused)",
                 "launches_per_step": n_x, "avg_launch_us": x_ms / n_x * 1e3, "algorithmic_tflop_per_step": x_fl / 1e12}
+        if world == 1 and a.stacked > 1:
+            try:
+                res["roofline_ip_attn_cfg4"] = ip_attn_cfg4(device, dtype)
+            except Exception as e:      # noqa: BLE001
+                res["roofline_ip_attn_cfg4"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.in_flight > 1:
             # extra, NOT the headline: several batch-1 candidates in flight on the one GPU (what PNS does with N > n_gpus)
             try:

@@ -26,7 +26,10 @@ from . import lib as L
 from .ctx import Ctx
 
 HEAD_DIM = 64
-DUAL_WS = os.environ.get("IMH_DUAL_WS", "1") != "0"     # A/B: the wave-specialised projection pair of self-attention
+# the wave-specialised projection pair of self-attention (imh_gemm_dual variant 24128).  Off by default: measured 45.7 us per
+# launch in the forward against 36.9 for the two-stage 128-row tiles (profiles/r03_forward_ab_dualws.json) -- its 416 workgroups
+# run as two rounds of one workgroup per CU, and both forms are bound by the same L2 -> LDS rate
+DUAL_WS = os.environ.get("IMH_DUAL_WS", "0") != "0"
 
 
 def _pad64(n):

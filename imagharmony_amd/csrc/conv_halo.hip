@@ -152,31 +152,26 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, c
         }
     }
 
-    // ---- epilogue: lane owns couts nb .. nb + 4 FN - 1 of output pixel (oy, ox), stored as 4-column pieces (compile-time
-    //      indices: a rolled loop would turn acc[][] into a scratch array) ----
+    // ---- epilogue: lane owns couts nb .. nb + 4 FN - 1 (40 or 20 consecutive channels = 80 / 40 B) of output pixel (oy, ox):
+    //      the whole run goes through the shared vector epilogue at once -- bias / time-embedding row / residual fetched as
+    //      16-B vectors once per run and the result stored as 16-B pieces.  (Round 2 stored 4-channel = 8-B pieces, 64
+    //      different 128-B lines per store instruction: profiles/r02_pmc_hbm_traffic.json showed 3.2x write amplification on
+    //      this kernel.)  Compile-time fragment indices only: a rolled loop would turn acc[][] into a scratch array.
     const int nb = n0 + wn * (16 * FN) + (lane >> 4) * (4 * FN);
     const int ox = tx * CH_PW + (lane & 15);
-    auto piece = [&](auto I, auto J, int m) {
-        constexpr int i = decltype(I)::value, j = decltype(J)::value;
-        if constexpr (j < FN && i < FM) {
-            float v[4];
-            const float none[8] = {};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            epilogue_store_pre<T, 1>(p, v, m, nb + 4 * j, none, false);
-        }
-    };
     auto row = [&](auto I) {
         constexpr int i = decltype(I)::value;
-        if constexpr (i >= FM) return;
-        const int oy = ty * CH_PH + FM * wm + (i < FM ? i : 0);
-        if (oy >= p.Ho || ox >= p.Wo || nb >= p.N) return;
-        const int m = (b * p.Ho + oy) * p.Wo + ox;
-        piece(I, std::integral_constant<int, 0>{}, m); piece(I, std::integral_constant<int, 1>{}, m);
-        piece(I, std::integral_constant<int, 2>{}, m); piece(I, std::integral_constant<int, 3>{}, m);
-        piece(I, std::integral_constant<int, 4>{}, m); piece(I, std::integral_constant<int, 5>{}, m);
-        piece(I, std::integral_constant<int, 6>{}, m); piece(I, std::integral_constant<int, 7>{}, m);
-        piece(I, std::integral_constant<int, 8>{}, m); piece(I, std::integral_constant<int, 9>{}, m);
+        if constexpr (i < FM) {
+            const int oy = ty * CH_PH + FM * wm + i;
+            if (oy >= p.Ho || ox >= p.Wo || nb >= p.N) return;
+            const int m = (b * p.Ho + oy) * p.Wo + ox;
+            float v[4 * FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+            epilogue_store<T, FN>(p, v, m, nb);
+        }
     };
     row(std::integral_constant<int, 0>{});
     row(std::integral_constant<int, 1>{});

@@ -52,11 +52,27 @@ double run(const unsigned char* src, size_t window, size_t stride, int wgs, int 
     return bytes / (ms * 1e-3) / 1e9;     // GB/s aggregate
 }
 
-int main() {
+int main(int argc, char**) {
     const size_t total = 1ull << 30;
     unsigned char* buf; hipMalloc(&buf, total); hipMemset(buf, 1, total);
     float* sink; hipMalloc(&sink, 4);
     printf("mode, src, wg/CU, D(in flight per wave), GB/s aggregate, GB/s per CU\n");
+    if (argc > 1) {
+        // L2 rates (round 3): windows that MISS the 32 KB vector L1 and HIT the 4 MB L2 of the XCD -- private 64 KB per
+        // workgroup (32 CUs x 64 KB = 2 MB per XCD) and one 1 MB window shared by every workgroup (the GEMM pattern:
+        // all CUs of an XCD stream the same operand panel)
+        printf("mode, src, wg/CU, D(in flight per wave), GB/s aggregate, GB/s per CU\n");
+        for (int shared = 0; shared <= 1; ++shared)
+            for (int wgpc : {1, 2}) {
+                const int wgs = 256 * wgpc;
+                const size_t window = shared ? (1u << 20) : (64u << 10);
+                const size_t stride = shared ? 0 : (64u << 10);
+#define RUN2(DD) do { const int iters = 4000 / DD; double a = run<DD, true>(buf, window, stride, wgs, iters, sink); \
+                printf("LDS-DMA, %s, %d, %d, %.0f, %.1f\n", shared ? "L2 shared 1 MB window" : "L2 private 64 KB windows", wgpc, DD, a, a / 256); } while (0)
+                RUN2(4); RUN2(8); RUN2(16);
+            }
+        return 0;
+    }
     for (int resident = 1; resident >= 0; --resident) {
         for (int wgpc : {1, 2, 4}) {
             const int wgs = 256 * wgpc;

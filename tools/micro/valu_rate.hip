@@ -9,10 +9,11 @@ typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(16))) float f16v;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 
-enum Op { EXP32 = 0, EXP16, FMA32, PKFMA, PKADD, PKMUL, MAX3, CVTPK, LDEXP, PERM32, MFMA32, MFMA_EXP2, MFMA_EXP1_FMA4, MFMA_FMA6, NOPS };
+enum Op { EXP32 = 0, EXP16, FMA32, PKFMA, PKADD, PKMUL, MAX3, CVTPK, LDEXP, PERM32, MFMA32, MFMA_EXP2, MFMA_EXP1_FMA4, MFMA_FMA6, MFMA32_FP8, MFMA32_MXFP8, CVT_FP8, NOPS };
 static const char* NAMES[] = {"v_exp_f32", "v_exp_f16", "v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_max3_f32",
                               "v_cvt_pk_bf16_f32", "v_ldexp_f32", "v_permlane32_swap", "mfma_32x32x16_bf16", "mfma + 2 v_exp_f32",
-                              "mfma + 1 v_exp_f32 + 4 v_fma_f32", "mfma + 6 v_fma_f32"};
+                              "mfma + 1 v_exp_f32 + 4 v_fma_f32", "mfma + 6 v_fma_f32", "mfma_32x32x16_fp8_fp8 (non-scaled)",
+                              "mfma_scale_32x32x64_f8f6f4 (MX fp8, K = 64)", "v_cvt_pk_fp8_f32"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, int iters) {
@@ -22,6 +23,9 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, i
     f2 y[4] = {{seed, seed}, {seed, seed}, {seed, seed}, {seed, seed}};
     f16v acc = {};
     bf8 a = {}, b = {};
+    long la = threadIdx.x, lb = 3;
+    typedef __attribute__((ext_vector_type(8))) int i8v;
+    i8v wa = {1, 2, 3, 4, 5, 6, 7, 8}, wb = {1, 2, 3, 4, 5, 6, 7, 8};
     unsigned u = threadIdx.x;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
@@ -49,6 +53,9 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, i
                     asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %4, %4, %4, %4"
                                  : "+v"(x[i]), "+v"(x[(i + 1) & 7]), "+v"(x[(i + 2) & 7]), "+v"(x[(i + 3) & 7]), "+v"(x[(i + 4) & 7]));
                 }
+                if (OP == MFMA32_FP8) acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(la, lb, acc, 0, 0, 0);
+                if (OP == MFMA32_MXFP8) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, wb, acc, 0, 0, 0, 127, 0, 127);
+                if (OP == CVT_FP8) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(u) : "v"(x[i]), "v"(x[(i + 1) & 7]));
                 if (OP == MFMA_FMA6) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
                     asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %4, %4, %4, %4\n\tv_fma_f32 %5, %5, %5, %5"
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, i
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += x[i];
-    s += y[0][0] + y[1][1] + y[2][0] + y[3][1] + acc[0] + acc[15];
+    s += y[0][0] + y[1][1] + y[2][0] + y[3][1] + acc[0] + acc[15] + (float)u;
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = (t1 - t0) + (s == 1234.5f ? 1 : 0);
 }
 
@@ -90,6 +97,6 @@ int main() {
     printf("op (group),waves_per_simd,cycles_per_group_per_wave,groups_per_clk_per_simd\n");
     run<EXP32>(d_out); run<EXP16>(d_out); run<FMA32>(d_out); run<PKFMA>(d_out); run<PKADD>(d_out); run<PKMUL>(d_out);
     run<MAX3>(d_out); run<CVTPK>(d_out); run<LDEXP>(d_out); run<PERM32>(d_out); run<MFMA32>(d_out); run<MFMA_EXP2>(d_out);
-    run<MFMA_EXP1_FMA4>(d_out); run<MFMA_FMA6>(d_out);
+    run<MFMA_EXP1_FMA4>(d_out); run<MFMA_FMA6>(d_out); run<MFMA32_FP8>(d_out); run<MFMA32_MXFP8>(d_out); run<CVT_FP8>(d_out);
     return 0;
 }
