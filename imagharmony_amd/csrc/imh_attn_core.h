@@ -21,6 +21,13 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// FIRST read of freshly issued MFMA accumulators: compiler-visible (fmaxf), so that hipcc's hazard recogniser inserts the
+// MFMA -> VALU wait states.  max3f() above is inline asm: hipcc pads nothing for an asm consumer (cdna_hip_programming.md 5.7
+// item 2), and a v_max3 that issues before the producing MFMA has retired reads stale registers -- the softmax stays
+// mathematically valid for any row maximum, so results only wobble in the last bits, run to run (found as a bitwise
+// non-determinism of the pipelined key loop).  Once one element of an accumulator has been read this way the whole MFMA has
+// retired and the asm reads that follow are safe.
+__device__ __forceinline__ float mfma_first_max(float a, float b) { return __builtin_fmaxf(a, b); }
 // max over the two half-waves (lanes l and l^32) without LDS: v_permlane32_swap leaves {lo,lo} / {hi,hi}
 __device__ __forceinline__ float xhalf_max(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -166,9 +173,9 @@ __device__ __forceinline__ void attn_core(const AttnParams& p, unsigned char* sm
                     for (int r = 0; r < 16; ++r)
                         if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
             }
-            float mx = max3f(st[0][0], st[1][0], st[0][1]);
+            float mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
             if (!(ATT_ABL & 8)) {
-                mx = max3f(mx, st[1][1], st[0][2]);
+                mx = fmaxf(mx, st[0][2]);
 #pragma unroll
                 for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
                 mx = fmaxf(mx, st[1][15]);
@@ -273,8 +280,8 @@ __device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigne
             for (int r = 0; r < 16; ++r)
                 if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
     }
-    float mx = max3f(st[0][0], st[1][0], st[0][1]);
-    mx = max3f(mx, st[1][1], st[0][2]);
+    float mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
+    mx = fmaxf(mx, st[0][2]);
 #pragma unroll
     for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
     mx = fmaxf(mx, st[1][15]);
@@ -395,8 +402,8 @@ __device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned cha
     // row maximum (lane-local row, one cross-half exchange)
     auto rowmax = [&](f32x16 (&st)[2], const int tile) -> float {
         (void)tile; (void)hi;
-        float mx = max3f(st[0][0], st[1][0], st[0][1]);
-        mx = max3f(mx, st[1][1], st[0][2]);
+        float mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
+        mx = fmaxf(mx, st[0][2]);
 #pragma unroll
         for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
         mx = fmaxf(mx, st[1][15]);
@@ -509,8 +516,10 @@ __device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned cha
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {                             // 32 scores in 8 slices of 4: two v_max3 each
                 constexpr int k2 = j >> 2, r0 = (j & 3) * 4;
-                mx = max3f(mx, nxt[k2][r0], nxt[k2][r0 + 1]);
-                mx = max3f(mx, nxt[k2][r0 + 2], nxt[k2][r0 + 3]);
+                if constexpr ((j & 3) == 0) mx = max3f(mfma_first_max(mx, nxt[k2][r0]), nxt[k2][r0 + 1], nxt[k2][r0 + 2]);   // see mfma_first_max
+                else mx = max3f(mx, nxt[k2][r0], nxt[k2][r0 + 1]);
+                if constexpr ((j & 3) == 0) mx = fmaxf(mx, nxt[k2][r0 + 3]);
+                else mx = max3f(mx, nxt[k2][r0 + 2], nxt[k2][r0 + 3]);
                 if constexpr (j >= 2 && j < 6 && stg != 0) {     // ... and one of the four LDS-DMA pieces of tile t + 3
                     if (stage_more) stage_piece(t + 3, j - 2);
                 }

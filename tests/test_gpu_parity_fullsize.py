@@ -25,12 +25,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
-# one forward: ~500 dependent launches, 70 transformer blocks, K up to 23040
-TOL_FWD = {torch.bfloat16: 5e-2, torch.float16: 8e-3}
-# configs[0]: 10 DDIM steps at 512^2 (CFG 5 amplifies the cond/uncond difference of every step)
-TOL_TRAJ10 = {torch.bfloat16: 8e-2}
-# 30 steps, reduced width
-TOL_TRAJ30 = {torch.bfloat16: 6e-2, torch.float16: 1.2e-2}
+# Bounds = about twice the values MEASURED on the MI355X this round (profiles/r03_parity.json; the kernels are deterministic, so
+# the measured numbers reproduce bit for bit):
+# one forward (~500 dependent launches, 70 transformer blocks, K up to 23040): measured bf16 1.15e-2, fp16 1.30e-3
+TOL_FWD = {torch.bfloat16: 2.5e-2, torch.float16: 3e-3}
+# configs[0]: 10 DDIM steps at 512^2 (CFG 5 amplifies the cond/uncond difference of every step): measured 3.46e-2
+TOL_TRAJ10 = {torch.bfloat16: 7e-2}
+# 30 steps, reduced width: measured bf16 1.34e-2, fp16 1.80e-3
+TOL_TRAJ30 = {torch.bfloat16: 3e-2, torch.float16: 4e-3}
 
 
 def _threads():
@@ -99,7 +101,7 @@ def _set_ip_tokens(unet, T):
 
 # BASELINE.json configs[3] (batch 4 per GPU, 16 Resampler tokens, fp16) and configs[4] (4 PNS candidates per GPU, 2 x 16
 # image tokens, bf16): UNet batch 8 runs OTHER tile variants (M = 8192 x N = 1280 ...) than the batch-2 forward above
-TOL_FWD_B8 = {torch.bfloat16: 5e-2, torch.float16: 8e-3}
+TOL_FWD_B8 = {torch.bfloat16: 2.8e-2, torch.float16: 3.5e-3}      # measured: bf16 (T = 32) 1.33e-2, fp16 (T = 16) 1.69e-3
 
 
 @pytest.mark.parametrize("dtype,T", [(torch.float16, 16), (torch.bfloat16, 32)])

@@ -1,7 +1,7 @@
 """GPU parity of the HIP attention processors (the diffusers AttentionProcessor plug-in boundary)
 against the golden vectors minted from the reference's own IPAttnProcessor2_0 / AttnProcessor2_0
-(tests/golden/attn_*.pt, oracle/gen_golden.py).  Tolerances from SURVEY.md 8c / BASELINE.md 4:
-fp16 rel-RMS <= 2e-3, bf16 <= 1.5e-2 (measured dtype noise of the reference itself: 6e-4 / 4.8e-3)."""
+(tests/golden/attn_*.pt, oracle/gen_golden.py).  Tolerances: fp16 rel-RMS <= 1.5e-3, bf16 <= 1.2e-2 = about twice what the
+kernels measure (profiles/r03_parity.json; the dtype noise of the reference itself is 6e-4 / 4.8e-3)."""
 import os
 
 import pytest
@@ -13,7 +13,7 @@ from oracle.gen_golden import ATTN_CASES, attn_inputs, make_attn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}      # about twice the measured maxima (7.3e-4 / 5.7e-3, profiles/r03_parity.json)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -41,7 +41,7 @@ def test_ip_processor_matches_reference_golden(case, dtype):
 
 # the shapes the benchmarked forward runs (cfg2: 1024^2, CFG batch 2; cfg4: batch 8, 16 Resampler tokens) against the
 # verbatim reference classes' outputs (sampled rows + whole-tensor row / column sums, oracle/gen_golden.py)
-TOL_CFG = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+TOL_CFG = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
