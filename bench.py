@@ -200,9 +200,9 @@ def lds_operand_bytes(shape, epi, esz=2):
         return 0.0
     M, N, K, conv, geom = shape
     bm, bn, sp = epi["cfg"]
-    if bm in (7128, 7564):
+    if bm in (7128, 7564, 7328, 7428):
         B, H, W, Cin, stride, up = geom
-        ph = 8 if bm == 7128 else 4
+        ph = 4 if bm == 7564 else 8
         Ho, Wo = H << up, W << up
         tiles = B * -(-Ho // ph) * -(-Wo // 16) * -(-N // bn)
         return float(tiles) * (Cin // 64) * ((ph + 2) * 18 * 128 + 9 * bn * 128)

@@ -28,8 +28,33 @@ constexpr int CH_HW = CH_PW + 2;                          // halo row length (18
 // 5 -> 160 couts (twice the workgroups: 256 at the 64^2 latent with 640 channels)
 // FM = token fragments (patch rows) per wave: 2 -> 8 x 16 patch (128 pixels), 1 -> 4 x 16 patch (64 pixels: twice the
 // workgroups again, for the 32^2 latent)
-template <typename T, int FN, int FM>
-__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
+// S = weight-tile ring depth.  Round 2 ran two stages and drained the LDS-DMA queue (vmcnt(0)) before every step's barrier,
+// which also waited for the next chunk's halo although it has nine steps of slack; now the weights are an S-slot ring with
+// COUNTED vmcnt (S - 2 steps and, where one was issued inside the window, the next halo stay in flight across the barrier).
+// S = 3 / 4 fit for the 160-cout form (107 / 127 KB); the 320-cout form stays at S = 2 (126 KB).
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
+    switch (n) {       // wave-uniform; the immediate must be a literal
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+}
+
+template <typename T, int FN, int FM, int S>
+__global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
     constexpr int CH_PH = 4 * FM;                           // output patch height
     constexpr int CH_HALO = (CH_PH + 2) * CH_HW;            // 180 / 108 halo pixels
     constexpr int HPIECES = (CH_HALO + 7) / 8;              // 23 / 14 staging pieces of 8 halo pixels
@@ -43,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo0 = smem;
     unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
+    static_assert(S >= 2 && (S - 2) * WQ + HQ <= 15, "vmcnt switch range");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,22 +142,32 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, c
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = 9 * cpt;
-    stage_halo(0, 0);
-    stage_w(0, 0, 0);
+    // LDS-DMA instructions this wave issues per weight step / per halo (wave-uniform: the last round of pieces is ragged)
+    const int nW = (WQ - 1) + ((WQ - 1) * 8 + wave < WPIECES ? 1 : 0);
+    const int nH = (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
+    auto step_ct = [&](int st) { return st / 9; };
+    stage_halo(0, 0);                                   // oldest: whoever waits for weight step 0 has the first halo too
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j)
+        if (j < nsteps) stage_w(j % S, step_ct(j), j - 9 * step_ct(j));
     int step = 0;
     for (int ct = 0; ct < cpt; ++ct) {
         const unsigned char* hb = halo0 + (ct & 1) * CH_HALO_BYTES;
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap, ++step) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of step `step` (and of the halo) landed
+            // weight step `step` must have landed.  Younger loads that may stay in flight: the weight steps behind it (at most
+            // S - 2) and the next chunk's halo if it was issued inside that window (at tap 0 of this chunk, taps 1 .. S - 1 ago)
+            const int ahead = min(S - 2, nsteps - 1 - step);
+            const int halo_in_window = (tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
+            wait_vmcnt_dyn(ahead * nW + halo_in_window);
             __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
             asm volatile("" ::: "memory");
-            if (step + 1 < nsteps) {
-                const int nt = tap == 8 ? 0 : tap + 1;
-                stage_w((step + 1) & 1, tap == 8 ? ct + 1 : ct, nt);
+            if (step + S - 1 < nsteps) {
+                const int ns = step + S - 1, nct = step_ct(ns);
+                stage_w(ns % S, nct, ns - 9 * nct);                  // into the slot of step - 1
             }
             if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
-            const unsigned char* wb = wbuf0 + (step & 1) * CH_W_BYTES;
+            const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES;
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -178,11 +214,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p, c
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
-// variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts
+// variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts;
+// 7328 / 7428 = the 8 x 16 patch with a 3- / 4-slot weight ring (160 couts only)
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
     const int ph = bm == 7564 ? 4 : 8;
-    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160)) {
-        set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 only (stride=%d splits=%d Cin=%d bn=%d)", p.stride, p.splits, p.Cin, bn);
+    const int S = bm == 7328 ? 3 : (bm == 7428 ? 4 : 2);
+    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160) || (S > 2 && bn != 160)) {
+        set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 (160 only for the 3- / 4-slot rings) (stride=%d splits=%d Cin=%d bm=%d bn=%d)", p.stride, p.splits, p.Cin, bm, bn);
         return IMH_ERR_ARG;
     }
     if (p.Ho != (p.H << p.up) || p.Wo != (p.Wd << p.up)) { set_error("conv_halo: output size must equal the (upsampled) input size"); return IMH_ERR_SHAPE; }
@@ -190,15 +228,18 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     const int B = p.M / (p.Ho * p.Wo);
     const int tiles_x = (p.Wo + CH_PW - 1) / CH_PW, tiles_y = (p.Ho + ph - 1) / ph, tiles_n = (p.N + bn - 1) / bn;
     dim3 grid(B * tiles_y * tiles_x * tiles_n);
-    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + 2 * bn * GEMM_ROW_BYTES;
-#define IMH_CH2(TT, FNV, FMV) do { auto kern = conv_halo_kernel<TT, FNV, FMV>; static DynLdsOnce lds_once; \
+    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * bn * GEMM_ROW_BYTES;
+#define IMH_CH3(TT, FNV, FMV, SV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
-#define IMH_CH(TT, FNV) do { if (ph == 8) IMH_CH2(TT, FNV, 2); else IMH_CH2(TT, FNV, 1); } while (0)
-    if (dtype == IMH_DT_BF16) { if (bn == 320) IMH_CH(bf16_t, 10); else IMH_CH(bf16_t, 5); }
-    else { if (bn == 320) IMH_CH(f16_t, 10); else IMH_CH(f16_t, 5); }
+#define IMH_CH(TT) do { \
+        if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
+        else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
+        else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
+    if (dtype == IMH_DT_BF16) IMH_CH(bf16_t);
+    else IMH_CH(f16_t);
 #undef IMH_CH
-#undef IMH_CH2
+#undef IMH_CH3
     return check_launch("conv_halo_kernel");
 }
 
