@@ -200,9 +200,9 @@ def lds_operand_bytes(shape, epi, esz=2):
         return 0.0
     M, N, K, conv, geom = shape
     bm, bn, sp = epi["cfg"]
-    if bm in (7128, 7564, 7328, 7428):
+    if bm in (7128, 7564, 7328, 7428, 7256, 7356):
         B, H, W, Cin, stride, up = geom
-        ph = 4 if bm == 7564 else 8
+        ph = 4 if bm == 7564 else (16 if bm in (7256, 7356) else 8)
         Ho, Wo = H << up, W << up
         tiles = B * -(-Ho // ph) * -(-Wo // 16) * -(-N // bn)
         return float(tiles) * (Cin // 64) * ((ph + 2) * 18 * 128 + 9 * bn * 128)

@@ -211,15 +211,20 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     };
     row(std::integral_constant<int, 0>{});
     row(std::integral_constant<int, 1>{});
+    row(std::integral_constant<int, 2>{});
+    row(std::integral_constant<int, 3>{});
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
 // variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts;
-// 7328 / 7428 = the 8 x 16 patch with a 3- / 4-slot weight ring (160 couts only)
+// 7328 / 7428 = the 8 x 16 patch with a 3- / 4-slot weight ring (160 couts only); 7256 / 7356 = a 16 x 16 patch (256 pixels x 160
+// couts per workgroup, wave tile 64 pixels x 80 couts like the wave-specialised GEMM's consumers: per MFMA 0.45 fragment reads
+// instead of 0.6 and 24.6 KB instead of 42.5 KB of operands per step for the 320-channel convolutions at the 128 x 128 latent)
+// with a 2- / 3-slot weight ring
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
-    const int ph = bm == 7564 ? 4 : 8;
-    const int S = bm == 7328 ? 3 : (bm == 7428 ? 4 : 2);
-    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160) || (S > 2 && bn != 160)) {
+    const int ph = bm == 7564 ? 4 : ((bm == 7256 || bm == 7356) ? 16 : 8);
+    const int S = (bm == 7328 || bm == 7356) ? 3 : (bm == 7428 ? 4 : 2);
+    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160) || ((S > 2 || ph == 16) && bn != 160)) {
         set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 (160 only for the 3- / 4-slot rings) (stride=%d splits=%d Cin=%d bm=%d bn=%d)", p.stride, p.splits, p.Cin, bm, bn);
         return IMH_ERR_ARG;
     }
@@ -233,7 +238,8 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
 #define IMH_CH(TT) do { \
-        if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
+        if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
+        else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
     if (dtype == IMH_DT_BF16) IMH_CH(bf16_t);

@@ -370,7 +370,7 @@ int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t
 template <typename T>
 static int launch_typed(const GemmParams& p, int conv, int bm, int bn, hipStream_t stream) {
     int rc;
-    if (bm == 7128 || bm == 7564 || bm == 7328 || bm == 7428) {
+    if (bm == 7128 || bm == 7564 || bm == 7328 || bm == 7428 || bm == 7256 || bm == 7356) {
         if (!conv) { set_error("gemm: variant 7128 is the halo conv3x3 kernel"); return IMH_ERR_ARG; }
         rc = conv_halo_launch(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? IMH_DT_BF16 : IMH_DT_F16, bm, bn, stream);
     } else
@@ -480,7 +480,7 @@ void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 // statistics epilogue (imh_lnstats.h): a wave's four 16-lane groups own one slot of consecutive columns
 int gemm_stats_slot_width(int bm, int bn) {
     if ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return bn / 2;          // plain tiles: 2 x 2 waves
-    if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 33256) && bn == 160) return 80;   // wave-specialised, CN = 2
+    if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256) && bn == 160) return 80;   // wave-specialised, CN = 2
     if (bm == 24128 && bn == 128) return 64;
     return 0;
 }
@@ -498,7 +498,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 33256 || (bm == 1464 && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || (bm == 1464 && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
         set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }
@@ -510,7 +510,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
             return IMH_ERR_ARG;
         }
     }
-    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 33256)) {
+    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256)) {
         set_error("gemm: precomputed LayerNorm statistics need a plain tile or a wave-specialised variant (bm=%d)", bm);
         return IMH_ERR_ARG;
     }

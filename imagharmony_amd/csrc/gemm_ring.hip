@@ -833,260 +833,6 @@ int gemm_ws_dual_launch(const GemmParams& a, const GemmParams& b, int dtype, hip
     return IMH_ERR_DTYPE;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent form of the wave-specialised kernel for the launches that need SEVERAL tiles per CU (ff.net.0: 2048 x 10240 is
-// 512 tiles of 256 x 160): one workgroup per CU walks TPW = 2 tiles (bid, bid + gridDim.x: same XCD, same weight columns).
-// The producers run the LDS-DMA ring over the CONCATENATED K-tile stream of both tiles, so while the consumers are in the
-// epilogue of tile 0 (LayerNorm formula, bias, 40 exact-erf GELUs and the stores: ~4 us) the first S - 1 K tiles of tile 1
-// are already landing -- the second prologue (workgroup dispatch, address set-up, statistics merge, first-tile latency) is
-// gone and the epilogue of tile 0 is no longer followed by an empty pipe.  Folded LayerNorm, row form, statistics handed over
-// (LN = 2 of gemm_ws_body): the consumer threads merge the rows of BOTH tiles at kernel entry into two LDS areas.
-// Plain Linear only (no conv, no split-K); epilogue = the lean LN [+ GEGLU] form when the launch allows it, else the shared one.
-template <typename T, int BM, int BN, int CM, int CN, int S, int NP>
-__global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_wsp_kernel(const GemmParams p) {
-    constexpr int TPW = 2;
-    constexpr int NC = CM * CN;
-    constexpr int TM = BM / CM, TN = BN / CN;
-    constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr int NIX = BM / 8, NI = (BM + BN) / 8;
-    constexpr int LP = NI / NP, KX = NIX / NP;
-    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
-    constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;
-    static_assert(NI % NP == 0 && NIX % NP == 0 && (S - 2) * LP <= 63, "even split / vmcnt range");
-    static_assert(S * STAGE + TPW * BM * 8 <= 160 * 1024, "ring + the two statistics areas fit the LDS");
-    typedef typename Vec<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x, nblocks = gridDim.x;
-    const int nt = p.K / GEMM_BK;
-    const int G = TPW * nt;                        // K tiles of the whole stream
-
-    if (wave >= NC) {
-        // ------------------------------------------------------------------ producer
-        const int pw = wave - NC;
-        const unsigned char* zero = g_zero_page;
-        const unsigned char* base[LP];
-        int step[LP];
-        auto setup = [&](int j) {
-            int m0, n0;
-            xcd_tile<BM, BN>(p, bid + j * nblocks, m0, n0);
-#pragma unroll
-            for (int k = 0; k < LP; ++k) {
-                const int r = (k * NP + pw) * 8 + (lane >> 3);
-                if (k < KX) {
-                    const int c = stage_chunk_x(r, lane);
-                    const int m = m0 + r;
-                    const bool ok = m < p.M;
-                    base[k] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
-                    step[k] = ok ? GEMM_BK * (int)sizeof(T) : 0;
-                } else {
-                    const int row = r - BM;
-                    const int c = stage_chunk_w(row, lane, FN);
-                    const int n = n0 + row;
-                    const bool ok = n < p.N;
-                    base[k] = ok ? (const unsigned char*)p.W + ((size_t)n * p.ldw) * sizeof(T) + c * 16 : zero + c * 16;
-                    step[k] = ok ? GEMM_BK * (int)sizeof(T) : 0;
-                }
-            }
-        };
-        int cur_j = 0;
-        setup(0);
-        auto issue_g = [&](int g) {
-            const int j = g >= nt ? 1 : 0;
-            if (j != cur_j) { setup(j); cur_j = j; }
-            const int kt = g - j * nt;
-            unsigned char* st = smem + (g % S) * STAGE;
-#pragma unroll
-            for (int k = 0; k < LP; ++k) glds16(base[k] + (size_t)kt * step[k], st + (k * NP + pw) * 8 * GEMM_ROW_BYTES);
-        };
-#pragma unroll
-        for (int s2 = 0; s2 < S - 1; ++s2)
-            if (s2 < G) issue_g(s2);
-        if (S - 1 <= G) wait_vmcnt<(S - 2) * LP>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                         // K tile 0 has landed
-        for (int g = 0; g < G; ++g) {
-            if (g + S - 1 < G) issue_g(g + S - 1);            // into the slot K tile g - 1 was read from
-            if (g + S <= G) wait_vmcnt<(S - 2) * LP>();       // K tile g + 1 has landed
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-        }
-        tail_prefetch(p.pf_ptr, p.pf_bytes, bid, nblocks, tid - 64 * NC, 64 * NP);
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumer
-    const int wm = wave / CN, wn = wave % CN;
-    int xoff[2], woff[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int xr = wm * TM + (lane & 15);
-        const int wr = wn * TN + w_frag_row(lane & 15, 0, FN);
-        xoff[kk] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
-        woff[kk] = XT_BYTES + tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
-    }
-    f32x4 acc[FM][FN];
-    v8 xf[2][FM], wf[2][FN];
-    auto rd = [&](auto KK, int slot) {
-        constexpr int kk = decltype(KK)::value;
-        const unsigned char* st = smem + slot * STAGE;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) xf[kk][i] = *(const v8*)(st + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wf[kk][j] = *(const v8*)(st + woff[kk] + j * 4 * GEMM_ROW_BYTES);
-    };
-    auto mm = [&](auto KK) {
-        constexpr int kk = decltype(KK)::value;
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[kk][j], xf[kk][i], acc[i][j]);
-    };
-    const std::integral_constant<int, 0> K0{};
-    const std::integral_constant<int, 1> K1{};
-    auto interleave = [&]() {
-#pragma unroll
-        for (int k = 0; k < FM + FN; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
-    };
-    {                                              // (mean, rstd) of the rows of BOTH tiles -> the two LDS areas behind the ring
-        const int t = wave * 64 + lane;
-        if (t < BM) {
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                int m0, n0;
-                xcd_tile<BM, BN>(p, bid + j * nblocks, m0, n0);
-                const int m = m0 + t;
-                f32x2s mr = {0.f, 1.f};
-                if (m < p.M) mr = merge_row_stats(p.ln_stats, m, p.ln_slots, p.K, p.ln_eps);
-                *(f32x2s*)(smem + S * STAGE + (j * BM + t) * 8) = mr;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                  // K tile 0 has landed
-    asm volatile("" ::: "memory");
-    int slot = 0;
-    for (int j = 0; j < TPW; ++j) {
-        int m0, n0;
-        xcd_tile<BM, BN>(p, bid + j * nblocks, m0, n0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < FN; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < nt; ++i) {
-            rd(K0, slot);
-            if (i > 0) mm(K1);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            rd(K1, slot);
-            mm(K0);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this K tile has been read: its slot may be refilled
-            __builtin_amdgcn_s_barrier();                            // ... and the next one (of this or the next tile) has landed
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (++slot == S) slot = 0;
-        }
-        mm(K1);
-
-        // ---- epilogue of tile j (the producers are already filling the ring with tile j + 1)
-        const int nb = n0 + wn * TN + (lane >> 4) * 4 * FN;
-        constexpr int NV = 4 * FN;
-        float lnpre[2 * NV];
-        const bool have_pre = ln_preload<NV>(p, nb, lnpre);
-        float st_s[FM], st_q[FM];
-        {
-            const f32x2s* ex = (const f32x2s*)(smem + S * STAGE + j * BM * 8);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const f32x2s mr = ex[wm * TM + i * 16 + (lane & 15)];
-                st_s[i] = mr[0]; st_q[i] = mr[1];
-            }
-        }
-        if ((p.flags & ~(GF_LN_ROW | GF_GEGLU)) == 0 && !p.rowadd && !p.residual && epilogue_fast<T, NV>(p, nb) && have_pre) {
-            const bool geglu = p.flags & GF_GEGLU;
-            float bs[NV];
-            if (p.bias) ldv<T, NV>((const T*)p.bias + nb, bs);
-            else {
-#pragma unroll
-                for (int q = 0; q < NV; ++q) bs[q] = 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * TM + i * 16 + (lane & 15);
-                if (m >= p.M) continue;
-                float v[NV];
-#pragma unroll
-                for (int jj = 0; jj < FN; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = jj * 4 + r;
-                        v[q] = fma_nopk(st_q[i], fma_nopk(-st_s[i], lnpre[q], acc[i][jj][r]), lnpre[NV + q]) + bs[q];
-                    }
-                if (geglu) {
-                    float o[NV / 2];
-#pragma unroll
-                    for (int q = 0; q < NV / 2; ++q) o[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
-                    stv<T, NV / 2>((T*)p.Y + (size_t)m * p.ldy + (nb >> 1), o);
-                } else {
-                    stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
-                }
-            }
-        } else {
-            LnArgs<NV> ln;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * TM + i * 16 + (lane & 15);
-                if (m >= p.M || nb >= p.N) continue;
-                float v[NV];
-#pragma unroll
-                for (int jj = 0; jj < FN; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][jj][r];
-                ln.mean = st_s[i]; ln.rstd = st_q[i];
-                epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, &ln, nullptr, lane);
-            }
-        }
-    }
-}
-
-template <typename T>
-static int launch_wsp(const GemmParams& p, hipStream_t stream) {
-    constexpr int BM = 256, BN = 160, S = 3;
-    GemmParams q = p;
-    int tiles;
-    xcd_partition(q, BM, BN, &tiles);
-    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + 2 * BM * 8;
-    auto kern = gemm_wsp_kernel<T, BM, BN, 4, 2, S, 4>;
-    static DynLdsOnce lds_once;
-    lds_once.ensure((const void*)kern, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(tiles / 2), dim3(64 * 12), smem, stream, q);
-    return check_launch("gemm_wsp_kernel");
-}
-
-// variant 33256 x 160: persistent two-tiles-per-workgroup form of 23256 x 160.  Returns -100 when the launch does not qualify
-// (the caller then takes the plain wave-specialised kernel).
-static int try_wsp(const GemmParams& p, int dtype, hipStream_t stream) {
-    GemmParams q = p;
-    int tiles;
-    xcd_partition(q, 256, 160, &tiles);
-    const int tm = (p.M + 255) / 256, tn = (p.N + 159) / 160;
-    const bool exact = tiles == tm * tn && p.M % 256 == 0 && p.N % 160 == 0;      // no padding workgroups in the XCD cells
-    if (!exact || tiles % 16 != 0 || p.splits > 1 || p.K / GEMM_BK < 3 || !(p.flags & GF_LN_ROW) || !p.ln_stats)
-        return -100;       // the persistent form exists for the folded-LayerNorm launches with handed-over statistics only
-    if (dtype == IMH_DT_BF16) return launch_wsp<bf16_t>(p, stream);
-    if (dtype == IMH_DT_F16) return launch_wsp<f16_t>(p, stream);
-    return -100;
-}
-
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
 static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
@@ -1171,13 +917,7 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
 }
 
 int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream) {
-    if (bm == 33256 && bn == 160) {
-        if (!conv) {
-            const int rc = try_wsp(p, dtype, stream);
-            if (rc != -100) return rc;
-        }
-        bm = 23256;        // not a two-tiles-per-CU launch: the plain wave-specialised 256 x 160 kernel
-    }
+
     if (dtype == IMH_DT_BF16) return conv ? ring_typed<bf16_t, true>(p, bm, bn, stream) : ring_typed<bf16_t, false>(p, bm, bn, stream);
     if (dtype == IMH_DT_F16) return conv ? ring_typed<f16_t, true>(p, bm, bn, stream) : ring_typed<f16_t, false>(p, bm, bn, stream);
     set_error("gemm_ring: unknown dtype %d", dtype);

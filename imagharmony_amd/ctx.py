@@ -155,9 +155,9 @@ class Ctx:
     # ------------------------------------------------------------------ GEMM / conv
     # variant codes (include/imh.h): what each family can do, so that a tuning-table entry (keyed by shape only) is never
     # handed a launch it rejects
-    _WS = (1464, 2464, 24128, 23256, 33256)   # wave-specialised (gemm_ring.hip); 33256 = persistent two-tile form of 23256
+    _WS = (1464, 2464, 24128, 23256)          # wave-specialised (gemm_ring.hip)
     _PP = (8256, 9128, 9256)                  # ping-pong (gemm_pp.hip)
-    _HALO = (7128, 7564, 7328, 7428)          # LDS-halo conv3x3, stride 1 (73xx / 74xx: 3- / 4-slot weight ring)
+    _HALO = (7128, 7564, 7328, 7428, 7256, 7356)   # LDS-halo conv3x3, stride 1 (7328 / 7428: weight rings; 7256 / 7356: 16 x 16 patch)
 
     @classmethod
     def _variant_ok(cls, bm, sp, flags, conv, stride, ln_pre):
@@ -171,7 +171,7 @@ class Ctx:
                 return False
             if plain:
                 return True
-            return bm in cls._WS if ln_pre else (bm in cls._PP or bm in (2464, 24128, 23256, 33256))
+            return bm in cls._WS if ln_pre else (bm in cls._PP or bm in (2464, 24128, 23256))
         if bm in cls._PP and conv:
             return False
         return True

@@ -175,6 +175,8 @@ def test_gemm_vt_perm(L, dtype, cfg):
                                   dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(7128, 160, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7328, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(7428, 160, 1)),
                                   dict(B=1, H=24, W=16, Cin=192, Cout=320, cfg=(7428, 160, 1)), dict(B=2, H=32, W=32, Cin=320, Cout=640, cfg=(7328, 160, 1)),
+                                  dict(B=2, H=32, W=32, Cin=128, Cout=320, cfg=(7256, 160, 1)), dict(B=1, H=20, W=12, Cin=64, Cout=200, up=1, cfg=(7356, 160, 1)),
+                                  dict(B=1, H=24, W=40, Cin=192, Cout=160, cfg=(7356, 160, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=10, W=20, Cin=64, Cout=384, cfg=(7564, 320, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(1464, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(2464, 160, 1)),
                                   dict(B=1, H=24, W=24, Cin=64, Cout=160, stride=2, cfg=(2464, 160, 2)),

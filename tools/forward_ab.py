@@ -48,18 +48,19 @@ CONFIGS = collections.OrderedDict([
     ("d_all_lin640", dict(xattn=1, attn=2, dual_ws=True, xstats=False, tuning={"8192,640,640,0": [24128, 160, 1]})),
     # session H: persistent two-tile GEGLU kernel (33256), weight rings of the LDS-halo conv (7328 / 7428 x 160)
     ("h_base", dict()),
-    ("h_wsp", dict(tuning={"2048,10240,1280,0,1": [33256, 160, 1], "8192,5120,640,0,1": [33256, 160, 1]})),
     ("h_conv64_s3", dict(tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("h_conv64_s4", dict(tuning={f"8192,640,{k},1": [7428, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("h_conv128_s3", dict(tuning={f"32768,320,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640)})),
     ("h_conv128_s4", dict(tuning={f"32768,320,{k},1": [7428, 160, 1] for k in (2880, 5760, 8640)})),
+    ("i_conv128_p16", dict(tuning={f"32768,320,{k},1": [7256, 160, 1] for k in (2880, 5760, 8640)})),
+    ("i_conv128_p16_s3", dict(tuning={f"32768,320,{k},1": [7356, 160, 1] for k in (2880, 5760, 8640)})),
 ])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--configs", default="h_base,h_wsp,h_conv64_s3,h_conv64_s4,h_conv128_s3,h_conv128_s4")
+    ap.add_argument("--configs", default="h_base,i_conv128_p16,i_conv128_p16_s3")
     ap.add_argument("--stacked", type=int, default=1)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()

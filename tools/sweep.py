@@ -123,7 +123,7 @@ def sweep_shapes(rec, dtype, extra=None, base=None):
         if not conv:
             cands += [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
         elif geom[4] == 1:
-            cands += [(7128, 320, 1), (7128, 160, 1), (7564, 320, 1), (7564, 160, 1), (7328, 160, 1), (7428, 160, 1)]           # LDS-halo conv kernel (stride 1 only)
+            cands += [(7128, 320, 1), (7128, 160, 1), (7564, 320, 1), (7564, 160, 1), (7328, 160, 1), (7428, 160, 1), (7256, 160, 1), (7356, 160, 1)]           # LDS-halo conv kernel (stride 1 only)
         if extra:                      # incremental: the current table entry against the new variants only
             key = f"{M},{N},{K},{conv}"
             cands = [tuple(base[key])] if base and key in base else [tuple(ctx._config(M, N, K, conv, 0))]
