@@ -35,6 +35,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
     p.residual = a->residual; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.ln_eps = a->ln_eps;
     p.ln_stats = a->ln_stats; p.ln_stats_out = a->ln_stats_out; p.ln_slots = a->ln_slots; p.ln_slots_out = a->ln_slots_out;
+    p.gn_out = a->gn_out; p.gn_nblk = a->gn_nblk; p.gn_groups = a->gn_groups; p.gn_hw = a->gn_hw;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
@@ -53,7 +54,7 @@ static int do_gemm_dual(const imh_gemm_args* a, const imh_gemm_args* b, hipStrea
         if ((g->flags & (IMH_GF_LN_ROW | IMH_GF_LN_COL)) && (!g->ln_s || !g->ln_c || !(g->ln_eps > 0.f))) {
             set_error("gemm_dual: folded LayerNorm needs ln_s / ln_c / ln_eps > 0"); return IMH_ERR_ARG;
         }
-        if (g->ln_stats_out) { set_error("gemm_dual: no statistics epilogue"); return IMH_ERR_ARG; }
+        if (g->ln_stats_out || g->gn_out) { set_error("gemm_dual: no statistics epilogue"); return IMH_ERR_ARG; }
         if (g->ln_stats && (g->ln_slots <= 0 || g->K % g->ln_slots)) { set_error("gemm_dual: ln_slots=%d must divide K=%d", g->ln_slots, g->K); return IMH_ERR_ARG; }
     }
     if ((a->ln_stats == nullptr) != (b->ln_stats == nullptr) && ((a->flags | b->flags) & (IMH_GF_LN_ROW | IMH_GF_LN_COL))) {
@@ -137,6 +138,7 @@ static NormParams to_norm(const imh_norm_args* a) {
     NormParams p;
     p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.partial = a->partial;
     p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.rows = a->rows; p.eps = a->eps; p.silu = a->silu;
+    p.stats_blocks = a->stats_blocks;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return p;
 }
@@ -237,6 +239,7 @@ int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 }
 size_t imh_gemm_workspace_bytes(int M, int N, int splits) { return gemm_workspace_bytes(M, N, splits); }
 int imh_gemm_stats_slot_width(int bm, int bn) { return gemm_stats_slot_width(bm, bn); }
+int imh_gemm_gn_block_rows(int bm, int bn) { return gemm_gn_block_rows(bm, bn); }
 
 int imh_attention(const imh_attn_args* a, void* stream) { return do_attn(a, (hipStream_t)stream); }
 

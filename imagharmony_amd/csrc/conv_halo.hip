@@ -19,6 +19,7 @@
 #include "imh_common.h"
 #include "imh_kernels.h"
 #include "imh_gemm_epilogue.h"
+#include "imh_lnstats.h"
 
 namespace imh {
 
@@ -195,6 +196,12 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     //      this kernel.)  Compile-time fragment indices only: a rolled loop would turn acc[][] into a scratch array.
     const int nb = n0 + wn * (16 * FN) + (lane >> 4) * (4 * FN);
     const int ox = tx * CH_PW + (lane & 15);
+    // GroupNorm partials of the output for the GroupNorm that reads it (norm2 after conv1, the next block's norm after conv2):
+    // a wave's FM patch rows x 16 pixels are one partial block
+    constexpr int GNS = (4 * FN) / 10;
+    float gn_flat[2 * GNS];
+#pragma unroll
+    for (int k = 0; k < 2 * GNS; ++k) gn_flat[k] = 0.f;
     auto row = [&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (i < FM) {
@@ -206,13 +213,20 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
-            epilogue_store<T, FN>(p, v, m, nb);
+            const float none[8 * FN] = {};
+            epilogue_store_pre<T, FN>(p, v, m, nb, none, false, nullptr, nullptr, lane, gn_flat);
         }
     };
     row(std::integral_constant<int, 0>{});
     row(std::integral_constant<int, 1>{});
     row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{});
+    if (p.gn_out) {
+        float gs[GNS], gq[GNS];
+#pragma unroll
+        for (int k = 0; k < GNS; ++k) { gs[k] = gn_flat[k]; gq[k] = gn_flat[GNS + k]; }
+        gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, b, (ty * tiles_x + tx) * 4 + wm, nb, gs, gq, lane);
+    }
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 

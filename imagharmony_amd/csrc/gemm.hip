@@ -485,6 +485,16 @@ int gemm_stats_slot_width(int bm, int bn) {
     return 0;
 }
 
+// GroupNorm epilogue (imh_lnstats.h gn_emit): pixels per partial block = one wave's rows; needs lane runs of 20 / 40 channels
+int gemm_gn_block_rows(int bm, int bn) {
+    if ((bm == 1464 || bm == 2464) && bn == 160) return 32;
+    if ((bm == 24128 || bm == 23256) && bn == 160) return 64;
+    if (bm == 7128 || bm == 7328 || bm == 7428) return 32;
+    if (bm == 7564) return 16;
+    if (bm == 7256 || bm == 7356) return 64;
+    return 0;
+}
+
 size_t gemm_workspace_bytes(int M, int N, int splits) {
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
@@ -507,6 +517,19 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
         if (w == 0 || p.N % w || p.ln_slots_out != p.N / w || conv || p.splits > 1 || (p.flags & (GF_GEGLU | GF_VT_PERM | GF_OUT_F32))) {
             set_error("gemm: ln_stats_out needs a variant with a statistics epilogue (slot width %d for %dx%d), N %% width == 0, "
                       "ln_slots_out == N / width, a plain output (N=%d slots=%d flags=%d splits=%d conv=%d)", w, bm, bn, p.N, p.ln_slots_out, p.flags, p.splits, conv);
+            return IMH_ERR_ARG;
+        }
+    }
+    if (p.gn_out) {
+        const int rows = gemm_gn_block_rows(bm, bn);
+        const int cpg = p.gn_groups > 0 ? p.N / p.gn_groups : 0;
+        const bool halo = bm >= 7000 && bm < 8000;
+        if (rows == 0 || p.gn_groups <= 0 || p.N % p.gn_groups || (cpg != 10 && cpg != 20 && cpg != 40) || p.N % (halo ? bn : 80) ||
+            p.gn_hw <= 0 || p.gn_hw % rows || p.M % p.gn_hw || p.gn_nblk != p.gn_hw / rows || p.splits > 1 ||
+            (p.flags & (GF_GEGLU | GF_VT_PERM | GF_OUT_F32 | GF_LN_ROW | GF_LN_COL)) ||
+            (halo && (p.Ho % (rows * 4 / 16) || p.Wo % 16))) {
+            set_error("gemm: gn_out needs a variant with a GroupNorm epilogue (%d rows per block for %dx%d), 10 / 20 / 40 channels per group, "
+                      "whole tiles, gn_nblk == gn_hw / rows (N=%d groups=%d hw=%d nblk=%d M=%d flags=%d)", rows, bm, bn, p.N, p.gn_groups, p.gn_hw, p.gn_nblk, p.M, p.flags);
             return IMH_ERR_ARG;
         }
     }

@@ -682,6 +682,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     if (pre.ok && p.bias) ldv<T, 4 * FN>((const T*)p.bias + nb, pre.bias);
     LnArgs<4 * FN> ln;
     float st_s[FM], st_q[FM];
+    // GroupNorm partials of the output (for the GroupNorm that reads it; imh_lnstats.h gn_emit): sub-runs of 10 channels
+    constexpr int GNS = (4 * FN) % 10 == 0 ? (4 * FN) / 10 : 1;
+    float gn_s[GNS], gn_q[GNS], gn_flat[2 * GNS];
+#pragma unroll
+    for (int k = 0; k < GNS; ++k) { gn_s[k] = 0.f; gn_q[k] = 0.f; gn_flat[k] = 0.f; gn_flat[GNS + k] = 0.f; }
     if constexpr (LN == 3) {
         const f32x2s* ex = (const f32x2s*)(smem + S * STAGE);
 #pragma unroll
@@ -766,6 +771,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                     for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bs[j * 4 + r] + rr[i][j * 4 + r];
                 stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
                 if (p.ln_stats_out) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
+                if constexpr (NV % 10 == 0) {
+                    if (p.gn_out) gn_accumulate<T, NV>(v, gn_s, gn_q);
+                }
+            }
+            if constexpr (NV % 10 == 0) {
+                if (p.gn_out) {
+                    const int mw = m0 + wm * TM;
+                    if (mw < p.M) gn_emit<NV>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gn_s, gn_q, lane);
+                }
             }
             return;
         }
@@ -790,7 +804,16 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
             }
         } else {
             if constexpr (LN == 1 || LN == 2) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
-            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane);
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane,
+                                      (LN == 0 && (4 * FN) % 10 == 0) ? gn_flat : nullptr);
+        }
+    }
+    if constexpr (LN == 0 && (4 * FN) % 10 == 0) {
+        if (p.gn_out && p.splits == 1) {
+#pragma unroll
+            for (int k = 0; k < GNS; ++k) { gn_s[k] = gn_flat[k]; gn_q[k] = gn_flat[GNS + k]; }
+            const int mw = m0 + wm * TM;
+            if (mw < p.M) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gn_s, gn_q, lane);
         }
     }
 }

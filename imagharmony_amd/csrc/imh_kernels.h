@@ -24,6 +24,10 @@ struct GemmParams {
     const float* ln_stats;
     float* ln_stats_out;
     int ln_slots, ln_slots_out;
+    // GroupNorm statistics of THIS launch's output (NHWC rows = pixels), for the GroupNorm that reads it: per (sample, pixel block of
+    // one wave's rows, group) the (sum, sum of squares) of the values as stored -- the layout of the GroupNorm kernel's own first pass
+    float* gn_out;
+    int gn_nblk, gn_groups, gn_hw;
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;
@@ -39,7 +43,8 @@ struct GemmParams {
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 size_t gemm_workspace_bytes(int M, int N, int splits);
-int gemm_stats_slot_width(int bm, int bn);     // channels per ln_stats_out slot of a tile variant, 0 = no statistics epilogue
+int gemm_stats_slot_width(int bm, int bn);
+int gemm_gn_block_rows(int bm, int bn);         // pixels per gn_out block of a tile variant (one wave's rows), 0 = no GroupNorm epilogue     // channels per ln_stats_out slot of a tile variant, 0 = no statistics epilogue
 int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
 int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream);
 
@@ -100,6 +105,7 @@ struct NormParams {
     int rows;         // layer norm: rows
     float eps;
     int silu;
+    int stats_blocks; // group norm: > 0 = `partial` holds that many producer-written partial blocks per sample (no statistics pass)
     const void* pf_ptr;   // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
 };

@@ -53,6 +53,48 @@ __device__ __forceinline__ void emit_row_stats(float* stats, const int slots, co
     }
 }
 
+// GroupNorm partials from a GEMM / conv epilogue.  A lane accumulates (sum, sum of squares) of its NV = 20 / 40 consecutive output
+// channels in sub-runs of 10 (the finest SDXL group: C = 320 / 32) over its rows; here the 16 lanes of a 16-lane group (= 16 rows)
+// are added up, sub-runs merged to the group width cpg (10, 20 or 40 channels; at cpg = 40 with NV = 20 two neighbouring lane
+// groups form one group), and one lane per group stores the pair.  partial[((b * nblk + blk) * groups + g) * 2 + {0, 1}].
+template <int NV>
+__device__ __forceinline__ void gn_emit(float* out, const int nblk, const int groups, const int cpg, const int b, const int blk,
+                                        const int nb, float (&gs)[NV / 10], float (&gq)[NV / 10], const int lane) {
+    constexpr int NS = NV / 10;
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { gs[k] += __shfl_xor(gs[k], o, 64); gq[k] += __shfl_xor(gq[k], o, 64); }
+    float* base = out + ((size_t)b * nblk + blk) * groups * 2;
+    if (cpg == 10) {
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { f32x2s o2 = {gs[k], gq[k]}; *(f32x2s*)(base + (nb / 10 + k) * 2) = o2; }
+        }
+    } else if (cpg == 20) {
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; k += 2) { f32x2s o2 = {gs[k] + gs[k + 1], gq[k] + gq[k + 1]}; *(f32x2s*)(base + (nb / 20 + k / 2) * 2) = o2; }
+        }
+    } else {        // cpg == 40
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { s += gs[k]; q += gq[k]; }
+        if constexpr (NV == 20) { s = xor16_sum(s); q = xor16_sum(q); }      // lane groups (0,1) and (2,3) hold the two halves
+        if ((lane & (NV == 20 ? 31 : 15)) == 0) { f32x2s o2 = {s, q}; *(f32x2s*)(base + (nb / 40) * 2) = o2; }
+    }
+}
+// per-row accumulation of the lane's values as stored (rounded to T)
+template <typename T, int NV>
+__device__ __forceinline__ void gn_accumulate(const float* v, float (&gs)[NV / 10], float (&gq)[NV / 10]) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float r = to_f32(from_f32<T>(v[q]));
+        gs[q / 10] += r;
+        gq[q / 10] = __builtin_fmaf(r, r, gq[q / 10]);
+    }
+}
+
 // Consumer side: (mean, rstd) of one token row from its `slots` partials (equal counts K / slots each).  The loads of a
 // batch are unconditional (index clamped; a clamped duplicate enters the merge with weight 0): a guarded load would make
 // hipcc branch around and wait for every element.  One thread per row.

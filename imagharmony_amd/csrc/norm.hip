@@ -79,7 +79,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p
 
 // pass 2: finalise statistics (double), then y = silu?(x * scale[c] + shift[c]).
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk) {
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk, int nstat) {
     typedef typename Vec<T>::v8 v8;
     __shared__ float mean_s[64], rstd_s[64];
     __shared__ double part_s[16][64], part_q[16][64];
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
         const int g = t % 32, sl = t / 32;           // GN_THREADS = 512 -> 16 slices of 32 lanes
         for (int gg = g; gg < p.groups; gg += 32) {
             double s = 0.0, q = 0.0;
-            for (int k = sl; k < nblk; k += 16) {
-                const float* pp = p.partial + (((size_t)b * nblk + k) * p.groups + gg) * 2;
+            for (int k = sl; k < nstat; k += 16) {      // nstat partial blocks per sample: pass 1's, or the producing GEMM's
+                const float* pp = p.partial + (((size_t)b * nstat + k) * p.groups + gg) * 2;
                 s += pp[0]; q += pp[1];
             }
             part_s[sl][gg] = s; part_q[sl][gg] = q;
@@ -157,14 +157,17 @@ int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
     }
     if (!p.partial) { set_error("groupnorm: workspace missing"); return IMH_ERR_WORKSPACE; }
     const int nblk = gn_nblk(p.HW, p.C);
+    // stats_blocks > 0: `partial` already holds the (sum, sum of squares) of stats_blocks pixel blocks per sample, left behind by the
+    // epilogue of the GEMM / conv that wrote x (imh_gemm_args.gn_out): pass 1 is skipped
+    const int nstat = p.stats_blocks > 0 ? p.stats_blocks : nblk;
     dim3 grid(nblk, p.B);
     const size_t lds = 2 * (size_t)p.C * std::max(1, GN_THREADS / (p.C >> 3)) * sizeof(float);
     if (dtype == IMH_DT_BF16) {
-        hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
-        hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+        if (p.stats_blocks <= 0) hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
+        hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk, nstat);
     } else if (dtype == IMH_DT_F16) {
-        hipLaunchKernelGGL((gn_stats_kernel<f16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
-        hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+        if (p.stats_blocks <= 0) hipLaunchKernelGGL((gn_stats_kernel<f16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
+        hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk, nstat);
     } else { set_error("groupnorm: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
     return check_launch("groupnorm");
 }

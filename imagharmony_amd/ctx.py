@@ -194,13 +194,15 @@ class Ctx:
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             ln=None, stats_out=False, _args_only=False):
+             ln=None, stats_out=False, gn_out=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
         ln = (s, c, eps[, stats]) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
         (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' precomputed statistics
         (csrc/imh_lnstats.h), None -> the kernel takes them inside its K loop.
         stats_out=True: also return the row statistics of y for a LayerNorm-folding consumer -> (y, (tensor, slots)); they
-        come from the GEMM's own epilogue when the chosen variant has one, else from a row-statistics launch over y."""
+        come from the GEMM's own epilogue when the chosen variant has one, else from a row-statistics launch over y.
+        gn_out=(groups, hw): y is a GroupNorm input of hw rows per sample -> (y, gn) with gn = (partials, blocks per sample) from
+        the epilogue for groupnorm(stats=gn), or gn = None when the chosen variant has no such epilogue."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
         K = K if K is not None else x.shape[1]
@@ -240,19 +242,39 @@ class Ctx:
             if wd > 0 and N % wd == 0 and sp == 1 and not flags & (L.GF_GEGLU | L.GF_VT_PERM | L.GF_OUT_F32):
                 st = (self.new(M, N // wd, 2, dtype=torch.float32), N // wd)
                 a.ln_stats_out, a.ln_slots_out = st[0].data_ptr(), st[1]
+        gn = self._gn_epilogue(a, gn_out) if gn_out is not None and not _args_only else None
         es = x.element_size()
         if _args_only:
             return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + keep_ln
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual) + keep_ln + ((st[0],) if st else ()), shape=(M, N, K, 0, None),
+                   keep=(x, w, out, bias, rowadd, residual) + keep_ln + ((st[0],) if st else ()) + ((gn[0],) if gn else ()),
+                   shape=(M, N, K, 0, None),
                    epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
                             rows_per_batch=rows_per_batch, cfg=(bm, bn, sp), ln_pre=ln_stats is not None,
-                            ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None))
+                            ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None,
+                            gn_out=(gn[1], gn_out[0], gn_out[1]) if gn else None))
         if stats_out:
             if st is None:
                 st = self.row_stats(out.view(M, n_out) if out.dim() != 2 else out, descr=descr + ".row_stats")
             return out, st
+        if gn_out is not None:
+            return out, gn
         return out
+
+    def _gn_epilogue(self, a, gn_out):
+        """GroupNorm partials from the launch's epilogue (imh_gemm_args.gn_out) if its variant and shape have one: fills the
+        fields of a and returns (partials [B, blocks, groups, 2] fp32, blocks per sample), else None"""
+        groups, hw = gn_out
+        rows = self.lib.imh_gemm_gn_block_rows(a.bm, a.bn)
+        halo = a.bm in self._HALO
+        if (rows <= 0 or a.splits != 1 or a.N % groups or a.N // groups not in (10, 20, 40) or hw % rows or a.M % hw
+                or a.N % (a.bn if halo else 80) or a.flags & ~(L.GF_ACT_SILU | L.GF_ACT_GELU)
+                or (halo and (a.Ho % (rows // 4) or a.Wo % 16))):
+            return None
+        nblk = hw // rows
+        t = self.new(a.M // hw, nblk, groups, 2, dtype=torch.float32)
+        a.gn_out, a.gn_nblk, a.gn_groups, a.gn_hw = t.data_ptr(), nblk, groups, hw
+        return t, nblk
 
     def row_stats(self, x, descr="row_stats"):
         """LayerNorm statistics of token rows x [rows, C] in the hand-over format (one slot per row): the stand-alone
@@ -282,8 +304,9 @@ class Ctx:
         return o1, o2
 
     def conv3x3(self, x, w, bias=None, stride=1, up=0, residual=None, rowadd=None, ldra=0, out=None, cfg=None,
-                descr="conv3x3"):
-        """x: NHWC [B, H, W, Cin]; w: packed [Cout, 9*Cin]; returns NHWC [B, Ho, Wo, Cout]."""
+                descr="conv3x3", gn_groups=0):
+        """x: NHWC [B, H, W, Cin]; w: packed [Cout, 9*Cin]; returns NHWC [B, Ho, Wo, Cout]; with gn_groups > 0 (the output is
+        a GroupNorm input) -> (y, gn) as gemm(gn_out=...)."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
@@ -309,13 +332,14 @@ class Ctx:
         a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
+        gn = self._gn_epilogue(a, (gn_groups, Ho * Wo)) if gn_groups else None
         es = x.element_size()
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K,
-                   nbytes=es * (B * H * W * Cin + N * K + M * N), keep=(x, w, out, bias, rowadd, residual),
+                   nbytes=es * (B * H * W * Cin + N * K + M * N), keep=(x, w, out, bias, rowadd, residual) + ((gn[0],) if gn else ()),
                    shape=(M, N, K, 1, (B, H, W, Cin, stride, up)),
                    epi=dict(flags=0, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
-                            rows_per_batch=Ho * Wo, cfg=(bm, bn, sp)))
-        return out
+                            rows_per_batch=Ho * Wo, cfg=(bm, bn, sp), gn_out=(gn[1], gn_groups, Ho * Wo) if gn else None))
+        return (out, gn) if gn_groups else out
 
     # ------------------------------------------------------------------ attention
     def attention(self, q, k, vt, out, B, H, Lq, Lk, Lk_pad, ldq, ldk, ldvt, ldo, scale,
@@ -379,8 +403,9 @@ class Ctx:
         return out
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm"):
-        """x: [B, HW, C] (NHWC flattened)."""
+    def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm", stats=None):
+        """x: [B, HW, C] (NHWC flattened).  stats = (partials, blocks per sample) left by the producing launch's epilogue
+        (gemm(gn_out=...) / conv3x3(gn_groups=...)): the statistics pass over x is skipped."""
         self._chk(x, descr + ".x")
         B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
         if out is None:
@@ -388,11 +413,16 @@ class Ctx:
         a = L.NormArgs()
         a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(gamma), self._p(beta)
         # scratch use is confined to this op's two kernels (stream order), so the shared workspace is safe
-        a.partial = self.workspace(self.lib.imh_groupnorm_workspace_bytes(B, HW, Cc, groups)).data_ptr()
+        if stats is not None:
+            if tuple(stats[0].shape) != (B, stats[1], groups, 2) or stats[0].dtype != torch.float32:
+                raise L.ImhError(f"{descr}: statistics {tuple(stats[0].shape)} do not fit [{B}, {stats[1]}, {groups}, 2]")
+            a.partial, a.stats_blocks = stats[0].data_ptr(), int(stats[1])
+        else:
+            a.partial = self.workspace(self.lib.imh_groupnorm_workspace_bytes(B, HW, Cc, groups)).data_ptr()
         a.B, a.HW, a.C, a.groups, a.eps, a.silu, a.dtype = B, HW, Cc, groups, eps, int(silu), self.dt
         es = x.element_size()
-        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=3.0 * es * x.numel(),
-                   keep=(x, out, gamma, beta))
+        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=(2.0 if stats is not None else 3.0) * es * x.numel(),
+                   keep=(x, out, gamma, beta) + ((stats[0],) if stats is not None else ()))
         return out
 
     def layernorm(self, x, gamma, beta, eps, out=None, descr="layernorm"):

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
@@ -24,6 +24,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
                 ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
                 ("ln_stats", _vp), ("ln_stats_out", _vp), ("ln_slots", _i32), ("ln_slots_out", _i32),
+                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_groups", _i32), ("gn_hw", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
@@ -59,7 +60,7 @@ class SmallAttnArgs(C.Structure):
 class NormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("partial", _vp),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("rows", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("stats_blocks", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
 
 class EwArgs(C.Structure):
@@ -80,6 +81,7 @@ SYMBOLS = [
                                        C.POINTER(C.c_int)]),
     ("imh_gemm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("imh_gemm_stats_slot_width", C.c_int, [C.c_int, C.c_int]),
+    ("imh_gemm_gn_block_rows", C.c_int, [C.c_int, C.c_int]),
     ("imh_attention", C.c_int, [C.POINTER(AttnArgs), _vp]),
     ("imh_cross_attention", C.c_int, [C.POINTER(XAttnArgs), _vp]),
     ("imh_attention_small", C.c_int, [C.POINTER(SmallAttnArgs), _vp]),

@@ -44,6 +44,17 @@ LN_STATS_HANDOVER = os.environ.get("IMH_LN_STATS", "1") != "0"
 # it reads anyway, which measured faster in the forward than a dependent load chain at kernel entry (27.3 vs 28.4 us per
 # launch, profiles/r03_forward_ab_stats.json); so attn1's to_out leaves no statistics behind
 XATTN_STATS_HANDOVER = os.environ.get("IMH_XATTN_STATS", "0") != "0"
+# GroupNorm statistics the same way: the conv / GEMM that writes a GroupNorm input (conv1 -> norm2, conv2 / proj_out / the
+# stride-2 downsampler -> the next block's norm1 / Transformer2DModel.norm / conv_norm_out) leaves per-group (sum, sum of
+# squares) partials behind from its epilogue (imh_gemm_args.gn_out) and imh_groupnorm skips its statistics pass over the
+# tensor.  Inputs no epilogue covers (conv_in, the up path's channel concats) keep the two-pass GroupNorm.
+# False = every GroupNorm takes its own statistics (A/B; IMH_GN_STATS=0).
+GN_STATS_HANDOVER = os.environ.get("IMH_GN_STATS", "1") != "0"
+
+
+def _pair(r, paired):
+    """(tensor, statistics) of an emit call that returns a pair only when asked for statistics"""
+    return r if paired else (r, None)
 
 
 @dataclass
@@ -274,13 +285,14 @@ class Transformer2DModel(nn.Module):
             [BasicTransformerBlock(channels, heads, cross_attention_dim) for _ in range(n_layers)])
         self.proj_out = Linear(channels, channels)
 
-    def emit(self, ctx, x, kvs, st):
-        """x: NHWC [B, H, W, C] -> same shape (x is consumed)."""
+    def emit(self, ctx, x, kvs, st, gn_in=None, want_gn=False):
+        """x: NHWC [B, H, W, C] -> same shape (x is consumed).  gn_in: GroupNorm partials of x left by the launch that wrote it;
+        want_gn: also return those of the output (from proj_out's epilogue, None if its variant has none) -> (out, gn)."""
         B, Hh, Ww, C_ = x.shape
         L_ = Hh * Ww
         x2 = x.view(B * L_, C_)
         n = ctx.groupnorm(x.view(B, L_, C_), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps,
-                          silu=False, descr="t2d.norm")
+                          silu=False, descr="t2d.norm", stats=gn_in)
         blocks = list(self.transformer_blocks)
         ho = LN_STATS_HANDOVER and bool(blocks) and blocks[0].fused(L_)
         r = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in", stats_out=ho)
@@ -290,9 +302,11 @@ class Transformer2DModel(nn.Module):
             more = ho and i + 1 < len(blocks) and blocks[i + 1].fused(L_)
             r = blk.emit(ctx, h, B, L_, kv, st, stats=stats, want_stats=more)
             h, stats = r if more else (r, None)
-        out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out")
+        out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out",
+                       gn_out=(self.groups, L_) if want_gn else None)
+        out, gn = out if want_gn else (out, None)
         ctx.free(h); ctx.free(x)
-        return out.view(B, Hh, Ww, C_)
+        return (out.view(B, Hh, Ww, C_), gn) if want_gn else out.view(B, Hh, Ww, C_)
 
 
 class ResnetBlock2D(nn.Module):
@@ -307,31 +321,36 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(cin, cout, 1) if cin != cout else None
         self.temb_offset = 0    # column of this block inside the stacked time_emb_proj output
 
-    def emit(self, ctx, x, st, keep_input=False):
-        """x: NHWC [B, H, W, Cin] -> [B, H, W, Cout]; x is consumed unless keep_input."""
+    def emit(self, ctx, x, st, keep_input=False, gn_in=None, want_gn=False):
+        """x: NHWC [B, H, W, Cin] -> [B, H, W, Cout]; x is consumed unless keep_input.  GroupNorm statistics travel with the
+        tensors (GN_STATS_HANDOVER): gn_in = partials of x left by the launch that wrote it (None -> norm1 takes them itself),
+        conv1's epilogue leaves norm2's, and with want_gn conv2's leaves those of the output -> (out, gn or None)."""
         B, Hh, Ww, Cin = x.shape
         Cout = self.conv1.weight.shape[0]
         n = ctx.groupnorm(x.view(B, Hh * Ww, Cin), _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups,
-                          self.norm1.eps, silu=True, descr="res.norm1").view(B, Hh, Ww, Cin)
+                          self.norm1.eps, silu=True, descr="res.norm1", stats=gn_in).view(B, Hh, Ww, Cin)
         ra = st.temb_all[:, self.temb_offset:self.temb_offset + Cout]
         h = ctx.conv3x3(n, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
-                        descr="res.conv1")
+                        descr="res.conv1", gn_groups=self.groups if GN_STATS_HANDOVER else 0)
+        h, g2 = h if GN_STATS_HANDOVER else (h, None)
         ctx.free(n)
         n = ctx.groupnorm(h.view(B, Hh * Ww, Cout), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups,
-                          self.norm2.eps, silu=True, descr="res.norm2").view(B, Hh, Ww, Cout)
+                          self.norm2.eps, silu=True, descr="res.norm2", stats=g2).view(B, Hh, Ww, Cout)
         ctx.free(h)
         if self.conv_shortcut is not None:
             sc = ctx.gemm(x.view(B * Hh * Ww, Cin), self.conv_shortcut.packed(ctx), bias=_b(self.conv_shortcut, ctx),
                           descr="res.shortcut")
         else:
             sc = x.view(B * Hh * Ww, Cin)
-        out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2")
+        out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2",
+                          gn_groups=self.groups if want_gn else 0)
+        out, gn = out if want_gn else (out, None)
         ctx.free(n)
         if self.conv_shortcut is not None:
             ctx.free(sc)
         if not keep_input:
             ctx.free(x)
-        return out
+        return (out, gn) if want_gn else out
 
 
 class Downsample2D(nn.Module):
@@ -604,32 +623,39 @@ class UNet2DConditionModel(nn.Module):
                nbytes=2.0 * B * Hl * Wl * boc[0])
         skips = [x]
         h = x
+        # GroupNorm statistics travel with h: hg = the partials its writing launch left for the GroupNorm that reads it next
+        # (a resnet's norm1, a Transformer2DModel's norm, conv_norm_out), None where that launch has no such epilogue
+        # (conv_in, channel concats)
+        ho = GN_STATS_HANDOVER
+        G = cfg.norm_num_groups
+        hg = None
         # -- down --
         for bi, blk in enumerate(self.down_blocks):
             for i, r in enumerate(blk.resnets):
                 ctx.tag = 10 + bi
-                h = r.emit(ctx, h, st, keep_input=True)      # inputs are skip tensors: keep
+                h, hg = _pair(r.emit(ctx, h, st, keep_input=True, gn_in=hg, want_gn=ho), ho)      # inputs are skip tensors: keep
                 if blk.has_attn:
                     ctx.tag = 20 + bi
                     t2d = blk.attentions[i]
                     kvs = [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))]
-                    hin = h
-                    h = self._t2d_keep(ctx, t2d, hin, kvs, st)
+                    h, hg = _pair(t2d.emit(ctx, h, kvs, st, gn_in=hg, want_gn=ho), ho)
                 skips.append(h)
             if blk.downsamplers is not None:
                 ctx.tag = 10 + bi
                 d = blk.downsamplers[0].conv
-                h = ctx.conv3x3(h, d.packed(ctx), bias=_b(d, ctx), stride=2, descr="downsample")
+                h, hg = _pair(ctx.conv3x3(h, d.packed(ctx), bias=_b(d, ctx), stride=2, descr="downsample", gn_groups=G if ho else 0), ho)
                 skips.append(h)
         # -- mid --
         ctx.tag = 30
         mb = self.mid_block
-        h = mb.resnets[0].emit(ctx, h, st, keep_input=True)
+        h, hg = _pair(mb.resnets[0].emit(ctx, h, st, keep_input=True, gn_in=hg, want_gn=ho), ho)
         t2d = mb.attentions[0]
         ctx.tag = 31
-        h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st)
+        h, hg = _pair(t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st,
+                               gn_in=hg, want_gn=ho), ho)
         ctx.tag = 30
-        h = mb.resnets[1].emit(ctx, h, st)
+        h = mb.resnets[1].emit(ctx, h, st, gn_in=hg)
+        hg = None
         # -- up --
         for bi, blk in enumerate(self.up_blocks):
             for i, r in enumerate(blk.resnets):
@@ -637,31 +663,31 @@ class UNet2DConditionModel(nn.Module):
                 sk = skips.pop()
                 hc = ctx.concat(h, sk, descr="skip.concat")
                 ctx.free(h); ctx.free(sk)
-                h = r.emit(ctx, hc, st)
+                last = bi + 1 == len(self.up_blocks) and i + 1 == len(blk.resnets)
+                want = ho and (blk.has_attn or last)            # read next by a t2d.norm / conv_norm_out (else by a concat)
+                h, hg = _pair(r.emit(ctx, hc, st, want_gn=want), want)
                 if blk.has_attn:
                     ctx.tag = 50 + bi
                     t2d = blk.attentions[i]
-                    h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st)
+                    h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st, gn_in=hg)
+                    hg = None
             if blk.upsamplers is not None:
                 ctx.tag = 40 + bi
                 u = blk.upsamplers[0].conv
                 hu = ctx.conv3x3(h, u.packed(ctx), bias=_b(u, ctx), up=1, descr="upsample")
                 ctx.free(h)
-                h = hu
+                h, hg = hu, None
         # -- out --
         ctx.tag = 60
         Bh, Hh, Ww, C0 = h.shape
         n = ctx.groupnorm(h.view(B, Hh * Ww, C0), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx),
-                          cfg.norm_num_groups, cfg.norm_eps, silu=True, descr="conv_norm_out").view(B, Hh, Ww, C0)
+                          cfg.norm_num_groups, cfg.norm_eps, silu=True, descr="conv_norm_out", stats=hg).view(B, Hh, Ww, C0)
         ctx.free(h)
         out = ctx.conv3x3(n, self.conv_out.packed(ctx), bias=_b(self.conv_out, ctx), descr="conv_out")
         ctx.free(n)
         ctx.tag = 0
         return out.view(B, Hh * Ww, cfg.out_channels)
 
-    def _t2d_keep(self, ctx, t2d, x, kvs, st):
-        """Transformer2DModel whose input is NOT a skip tensor owner: Transformer2DModel.emit consumes x."""
-        return t2d.emit(ctx, x, kvs, st)
 
     def _pname(self, t2d, k):
         names = getattr(self, "_imh_pnames", None)

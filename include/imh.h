@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 4
+#define IMH_ABI_VERSION 5
 
 enum imh_status {
     IMH_OK = 0,
@@ -104,6 +104,15 @@ typedef struct imh_gemm_args {
     const float* ln_stats;
     float* ln_stats_out;
     int32_t ln_slots, ln_slots_out;
+    /* GroupNorm partials of THIS launch's output, for the imh_groupnorm that reads it (diffusers ResnetBlock2D.norm2 after
+     * conv1, the next block's norm1 / Transformer2DModel.norm after conv2 / conv_shortcut + residual): (sum, sum of squares)
+     * of the values as rounded to the output dtype, gn_out[((b * gn_nblk + blk) * gn_groups + g) * 2 + {0, 1}] fp32, one
+     * partial block per imh_gemm_gn_block_rows(bm, bn) consecutive rows (pixels) of a sample; gn_hw = rows per sample,
+     * gn_nblk = gn_hw / block rows.  Hand the buffer to imh_norm_args.partial with stats_blocks = gn_nblk.  NULL -> none.
+     * Variants with this epilogue: the wave-specialised ones at bn = 160 and the LDS-halo conv3x3; N / gn_groups must be
+     * 10, 20 or 40 (SDXL: 320 / 640 / 1280 channels, 32 groups); no split-K, GEGLU, V^T permutation, fp32 output, LN. */
+    float* gn_out;
+    int32_t gn_nblk, gn_groups, gn_hw;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -132,6 +141,8 @@ int imh_gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 /* channels per statistics slot written by tile variant (bm, bn) through ln_stats_out; 0 = the variant has no
  * statistics epilogue (use IMH_EW_ROW_STATS on its output instead) */
 int imh_gemm_stats_slot_width(int bm, int bn);
+/* rows per GroupNorm partial block written by tile variant (bm, bn) through gn_out; 0 = no such epilogue */
+int imh_gemm_gn_block_rows(int bm, int bn);
 size_t imh_gemm_workspace_bytes(int M, int N, int splits);
 
 /* ---- attention, head_dim 64 -------------------------------------------------------------
@@ -243,6 +254,9 @@ typedef struct imh_norm_args {
     float eps;
     int32_t silu;
     int32_t dtype;
+    /* imh_groupnorm only: > 0 -> `partial` already holds that many (sum, sum of squares) blocks per sample, written by the
+     * producing launch's gn_out epilogue (imh_gemm_args), and the statistics pass over x is skipped; 0 -> taken here */
+    int32_t stats_blocks;
     const void* pf_ptr;    /* tail prefetch of the next launch's weights (cache hint) */
     uint32_t pf_bytes;
 } imh_norm_args;

@@ -3,6 +3,7 @@ rounds inside one process).  Records the 1024^2 CFG-2 SDXL forward once per conf
 in interleaved rounds: per-op HIP-event times (min over rounds, summed by op family) and the back-to-back wall time of the
 plan (median over rounds).  Knobs per configuration:
     ln_stats   unet.LN_STATS_HANDOVER (LayerNorm statistics handed over from the producing GEMM's epilogue)
+    gn_stats   unet.GN_STATS_HANDOVER (GroupNorm statistics likewise)
     xattn      imh_debug_set(3, mode): 1 one head per workgroup, 2 / 3 / 4 two heads with 0 / 2 / 4 producer waves
     tuning     {"M,N,K,conv[,1]": [bm, bn, splits]} overrides on top of tuning.json
 Usage: python tools/forward_ab.py [--rounds 5] [--configs name1,name2,...] [--stacked S] > gpurun_out/forward_ab.json"""
@@ -54,13 +55,16 @@ CONFIGS = collections.OrderedDict([
     ("h_conv128_s4", dict(tuning={f"32768,320,{k},1": [7428, 160, 1] for k in (2880, 5760, 8640)})),
     ("i_conv128_p16", dict(tuning={f"32768,320,{k},1": [7256, 160, 1] for k in (2880, 5760, 8640)})),
     ("i_conv128_p16_s3", dict(tuning={f"32768,320,{k},1": [7356, 160, 1] for k in (2880, 5760, 8640)})),
+    # session J: GroupNorm statistics from the producing conv / GEMM epilogue (gn_stats)
+    ("j_gn_off", dict(gn_stats=False)),
+    ("j_gn_on", dict(gn_stats=True)),
 ])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--configs", default="h_base,i_conv128_p16,i_conv128_p16_s3")
+    ap.add_argument("--configs", default="j_gn_off,j_gn_on")
     ap.add_argument("--stacked", type=int, default=1)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
@@ -74,6 +78,7 @@ def main():
         c = CONFIGS[n]
         U.LN_STATS_HANDOVER = bool(c.get("ln_stats", True))
         U.XATTN_STATS_HANDOVER = bool(c.get("xstats", False))
+        U.GN_STATS_HANDOVER = bool(c.get("gn_stats", True))
         AP.DUAL_WS = bool(c.get("dual_ws", False))
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
