@@ -93,11 +93,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
     {   // 16 slices x groups threads sum the per-block partials, then a fixed-order combine (deterministic)
         const int g = t % 32, sl = t / 32;           // GN_THREADS = 512 -> 16 slices of 32 lanes
         for (int gg = g; gg < p.groups; gg += 32) {
+            // nstat partial blocks per sample: pass 1's, or the producing conv / GEMM's (up to 512 of them: eight independent
+            // 8-B loads in flight per thread -- one dependent load per step left this prologue at ~nstat / 16 L2 latencies)
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            const f2* pp = (const f2*)p.partial + ((size_t)b * nstat) * p.groups + gg;
             double s = 0.0, q = 0.0;
-            for (int k = sl; k < nstat; k += 16) {      // nstat partial blocks per sample: pass 1's, or the producing GEMM's
-                const float* pp = p.partial + (((size_t)b * nstat + k) * p.groups + gg) * 2;
-                s += pp[0]; q += pp[1];
+            int k = sl;
+            for (; k + 7 * 16 < nstat; k += 8 * 16) {
+                f2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(k + u * 16) * p.groups];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += v[u][0]; q += v[u][1]; }
             }
+            for (; k < nstat; k += 16) { const f2 v = pp[(size_t)k * p.groups]; s += v[0]; q += v[1]; }
             part_s[sl][gg] = s; part_q[sl][gg] = q;
         }
     }

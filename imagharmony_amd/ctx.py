@@ -180,8 +180,10 @@ class Ctx:
         """tile variant of a launch: the tuning table's entry for the shape if that variant implements the launch's flags
         (folded LayerNorm in either form, V^T permutation, conv stride), else the built-in heuristic -- in ONE place"""
         key = (M, N, K, int(conv))
-        # a fifth key field 1 = the entry for launches whose LayerNorm statistics are precomputed (other variants apply)
-        cfg = (self.tuning.get(key + (1,)) if ln_pre else None) or self.tuning.get(key)
+        # a fifth key field: 1 = the entry for launches whose LayerNorm statistics are precomputed (other variants apply);
+        # 2 = the entry for a stride-2 conv whose (M, N, K) coincides with a stride-1 conv of another resolution / batch
+        cfg = (self.tuning.get(key + (1,)) if ln_pre else self.tuning.get(key + (2,)) if conv and stride == 2 else None) \
+            or self.tuning.get(key)
         if cfg is not None and self._variant_ok(cfg[0], cfg[2], flags, conv, stride, ln_pre):
             return tuple(cfg)
         bm, bn, sp = C.c_int(), C.c_int(), C.c_int()

@@ -280,6 +280,40 @@ def test_folded_layernorm_launches_only_get_variants_that_implement_it():
     assert (a.bm, a.bn) == (1464, 160)                              # explicit: the C side is the one to refuse it
 
 
+def test_groupnorm_statistics_handover_host_logic():
+    """host logic of the GroupNorm-statistics hand-over (Ctx._gn_epilogue): a producing launch gets gn_out only when its tile
+    variant has the epilogue AND the shape fits it (10 / 20 / 40 channels per group, whole pixel blocks, no split-K); the
+    consumer's imh_norm_args then carries the producer's buffer and block count, else it keeps its own statistics pass"""
+    from imagharmony_amd import lib as L
+    from imagharmony_amd.ctx import Ctx
+    ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
+    bf = torch.bfloat16
+    x, w = torch.zeros(2, 32, 32, 64, dtype=bf), torch.zeros(320, 9 * 64, dtype=bf)
+    for cfg, rows in (((7128, 320, 1), 32), ((7564, 160, 1), 16), ((7256, 160, 1), 64), ((2464, 160, 1), 32), ((23256, 160, 1), 64),
+                      ((128, 128, 1), 0), ((2464, 160, 2), 0), ((24128, 128, 1), 0)):
+        assert ctx.lib.imh_gemm_gn_block_rows(cfg[0], cfg[1]) == (rows if cfg != (2464, 160, 2) else 32)
+        y, gn = ctx.conv3x3(x, w, cfg=cfg, gn_groups=32)
+        epi = ctx.tags[-1][6]
+        if rows:
+            assert gn is not None and gn[1] == 1024 // rows and tuple(gn[0].shape) == (2, 1024 // rows, 32, 2) and gn[0].dtype == torch.float32
+            assert epi["gn_out"] == (1024 // rows, 32, 1024)
+            n = ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True, stats=gn)
+            a = ctx._ops[-1][1]
+            assert a.stats_blocks == gn[1] and a.partial == gn[0].data_ptr()
+        else:
+            assert gn is None and epi["gn_out"] is None
+            ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True)
+            assert ctx._ops[-1][1].stats_blocks == 0
+    # shapes off the grid: 12 channels per group, a patch grid that does not tile the image, rows per sample not a block multiple
+    assert ctx.conv3x3(x, torch.zeros(384, 9 * 64, dtype=bf), cfg=(7128, 160, 1), gn_groups=32)[1] is None
+    assert ctx.conv3x3(torch.zeros(1, 12, 20, 64, dtype=bf), w, cfg=(7128, 320, 1), gn_groups=32)[1] is None
+    xg, wg = torch.zeros(2 * 48, 64, dtype=bf), torch.zeros(320, 64, dtype=bf)
+    assert ctx.gemm(xg, wg, cfg=(23256, 160, 1), gn_out=(32, 48))[1] is None
+    assert ctx.gemm(torch.zeros(512, 64, dtype=bf), wg, cfg=(23256, 160, 1), gn_out=(32, 256))[1][1] == 4
+    with pytest.raises(L.ImhError, match="statistics"):
+        ctx.groupnorm(torch.zeros(2, 1024, 320, dtype=bf), None, None, 32, 1e-5, True, stats=(torch.zeros(2, 8, 16, 2), 8))
+
+
 def test_derived_weight_caches_follow_in_place_updates():
     """packed / LayerNorm-folded weight copies are cached on the modules; their keys carry the in-place version counter of
     every source tensor (weight, bias, norm.weight, norm.bias), so load_state_dict / weight.copy_ after a first forward

@@ -58,6 +58,10 @@ CONFIGS = collections.OrderedDict([
     # session J: GroupNorm statistics from the producing conv / GEMM epilogue (gn_stats)
     ("j_gn_off", dict(gn_stats=False)),
     ("j_gn_on", dict(gn_stats=True)),
+    # session K (--stacked 4): the S = 4 table; GEGLU with handed-over statistics on 128 x 128 instead of 256 x 160 ws
+    ("k_s4", dict()),
+    ("k_s4_geglu64_128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1]})),
+    ("k_s4_geglu_both128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1], "8192,10240,1280,0,1": [128, 128, 1]})),
 ])
 
 

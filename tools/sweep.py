@@ -119,7 +119,8 @@ def sweep_shapes(rec, dtype, extra=None, base=None):
                         continue
                     cands.append((bm, bn, sp))
         cands += [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3128, 128, 2), (3064, 64, 1),
-                  (4128, 64, 1), (5064, 64, 1), (4064, 128, 1), (6128, 320, 1), (5258, 320, 1)]
+                  (4128, 64, 1), (5064, 64, 1), (4064, 128, 1), (6128, 320, 1), (5258, 320, 1),
+                  (1464, 160, 1), (2464, 160, 1), (24128, 160, 1), (24128, 128, 1), (23256, 160, 1)]      # wave-specialised
         if not conv:
             cands += [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]
         elif geom[4] == 1:
