@@ -144,6 +144,43 @@ def cpu_baseline(res, ip_tokens, denoise_steps):
     return out
 
 
+def configs3_extra(device, res_px, S=4, T=16, steps=50):
+    """BASELINE.json configs[3]: SDXL 1024^2, 50 steps, batch 4 per GPU (S candidates stacked into one UNet batch of 2S with
+    CFG), Resampler num_queries = 16 (the 16 image tokens come out of the IP-Adapter-Plus-XL Resampler on the device:
+    ip_adapter.py:392-403), fp16.  Own fp16 UNet (random weights) + engine; one warm-up denoise, one timed."""
+    from imagharmony_amd import pns
+    from imagharmony_amd.modules import Resampler
+    from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
+    from imagharmony_amd.schedulers import DDIMScheduler
+    dtype = torch.float16
+    unet = build_unet(device, dtype, T)
+    rs = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=T, embedding_dim=1280, output_dim=2048, ff_mult=4).to(device, dtype).eval()
+    clip = torch.randn(2, 257, 1280, generator=torch.Generator("cpu").manual_seed(5)).to(device, dtype)
+    with torch.no_grad():
+        ip = rs(clip).float().cpu()                       # [2, T, 2048]: image tokens of the positive / negative branch
+    pe, ne, po, no = synthetic_conditioning(T)
+    pe[:, 77:], ne[:, 77:] = ip[:1], ip[1:]
+    pe, ne, po, no = [t.to(device) for t in (pe, ne, po, no)]
+    pipe = StableDiffusionXLCustomPipeline(unet, scheduler=DDIMScheduler(), device=device, dtype=dtype)
+    e = pipe.engine.__class__(unet, device, dtype, True)
+    e.set_conditioning(pe.repeat(S, 1, 1), ne.repeat(S, 1, 1), po.repeat(S, 1), no.repeat(S, 1), res_px, res_px, guidance_scale=5.0)
+    e.set_schedule(pipe.scheduler, steps)
+    z = torch.cat([pns.seed_latents(3000 + j, (1, 4, res_px // 8, res_px // 8)) for j in range(S)], 0).to(device)
+    e.denoise(z)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    o = e.denoise(z)
+    torch.cuda.synchronize(device)
+    dt_s = time.perf_counter() - t0
+    out = {"images_per_sec": S / dt_s, "ms_per_unet_forward": dt_s / steps * 1e3, "unet_batch": 2 * S, "denoise_steps": steps,
+           "ip_tokens": T, "dtype": "fp16", "scheduler": "DDIM", "outputs_finite": bool(torch.isfinite(o).all().item()),
+           "note": "BASELINE.json configs[3] on one GPU (never `value`): the 16 image tokens are produced by the Resampler on the "
+                   "device; parity of this shape family: tests/test_gpu_parity_fullsize.py (UNet batch 8, T = 16, fp16 vs the CPU oracle)"}
+    del e, pipe, unet, rs
+    torch.cuda.empty_cache()
+    return out
+
+
 def resampler_extra(device, dtype):
     """ms per call of the IP-Adapter-Plus-XL Resampler (ip_adapter/resampler.py:81-158 at the ip_adapter.py:392-403 config:
     dim 1280, depth 4, 20 heads x 64, 16 queries, 257 CLIP patch tokens -> [B, 16, 2048]) on the HIP kernels, eager and
@@ -440,10 +477,13 @@ def main():
                                            "instructions incl. 32 v_exp_f32 (~600 cycles of the VALU pipe, profiles/r03_valu_mfma_rate_microbench.csv)"},
             # what actually bounds the M = 2048 / 8192 layers: operand bytes through the L2 -> LDS path (LDS-DMA), see lds_operand_bytes
             "roofline_l2_lds": {"bound": "l2->lds", "achieved": g_lds / (g_lds_ms * 1e-3) / 1e12, "unit": "TB/s",
-                                "peak": 17.2, "frac": g_lds / (g_lds_ms * 1e-3) / 1e12 / 17.2,
+                                "peak": 36.5, "frac": g_lds / (g_lds_ms * 1e-3) / 1e12 / 36.5,
                                 "bytes_per_step": g_lds, "kernel": "same GEMM / conv family (dual launches excluded)",
-                                "note": "peak = 32 B/clk/CU x 256 CUs x 2.1 GHz (each XCD's L2 feeds its 32 CUs 1024 B/clk); the wave-specialised "
-                                        "kernels measure 58-67 GB/s per CU on every tile shape (profiles/r03_l2_lds_rate_microbench.csv)"},
+                                "note": "peak = the MEASURED LDS-DMA rate of L2-resident lines, every CU streaming (tools/micro/glds_rate.hip l2: "
+                                        "27.8 TB/s = 108 GB/s per CU with one workgroup per CU, 36.5 TB/s = 143 GB/s per CU with two; "
+                                        "profiles/r03_l2_lds_rate_microbench.csv), not a datasheet figure; bytes = operand tile bytes each "
+                                        "workgroup stages (lds_operand_bytes); the M = 2048 wave-specialised launches sustain 58-67 GB/s per CU "
+                                        "inside their K loops, i.e. the L2 path is NOT what bounds them (DESIGN.md 3)"},
         }
         if ip_us:
             kv_fl = 2.0 * 2 * 2 * (77 + a.ip_tokens) * 2048 * 1280          # text + ip K,V projections of one IP-active layer (CFG batch 2)
@@ -485,6 +525,12 @@ def main():
                                              "note": f"UNet batch {2 * a.stacked} (CFG); same arithmetic per image as `value`"}
             except Exception as e:      # noqa: BLE001
                 res["stacked_candidates"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and a.stacked > 1 and a.res == 1024:
+            # extra, NOT the headline: BASELINE.json configs[3] -- 50 steps, batch 4 per GPU, 16 image tokens from the Resampler, fp16
+            try:
+                res["configs3_fp16_50steps_batch4_T16"] = configs3_extra(device, a.res)
+            except Exception as e:      # noqa: BLE001
+                res["configs3_fp16_50steps_batch4_T16"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
             try:
                 from imagharmony_amd.vae import AutoencoderKL, decode_latents

@@ -480,7 +480,7 @@ void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 // statistics epilogue (imh_lnstats.h): a wave's four 16-lane groups own one slot of consecutive columns
 int gemm_stats_slot_width(int bm, int bn) {
     if ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return bn / 2;          // plain tiles: 2 x 2 waves
-    if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256) && bn == 160) return 80;   // wave-specialised, CN = 2
+    if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128) && bn == 160) return 80;   // wave-specialised, CN = 2
     if (bm == 24128 && bn == 128) return 64;
     return 0;
 }
@@ -488,7 +488,7 @@ int gemm_stats_slot_width(int bm, int bn) {
 // GroupNorm epilogue (imh_lnstats.h gn_emit): pixels per partial block = one wave's rows; needs lane runs of 20 / 40 channels
 int gemm_gn_block_rows(int bm, int bn) {
     if ((bm == 1464 || bm == 2464) && bn == 160) return 32;
-    if ((bm == 24128 || bm == 23256) && bn == 160) return 64;
+    if ((bm == 24128 || bm == 23256 || bm == 22128) && bn == 160) return 64;
     if (bm == 7128 || bm == 7328 || bm == 7428) return 32;
     if (bm == 7564) return 16;
     if (bm == 7256 || bm == 7356) return 64;
@@ -508,7 +508,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || (bm == 1464 && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || ((bm == 1464 || bm == 22128) && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
         set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }
@@ -533,7 +533,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
             return IMH_ERR_ARG;
         }
     }
-    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256)) {
+    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128)) {
         set_error("gemm: precomputed LayerNorm statistics need a plain tile or a wave-specialised variant (bm=%d)", bm);
         return IMH_ERR_ARG;
     }

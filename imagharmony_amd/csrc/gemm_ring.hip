@@ -818,8 +818,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     }
 }
 
-template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
-__global__ __launch_bounds__(64 * (CM * CN + NP), 1) void gemm_ws_kernel(const GemmParams p) {
+// OCC = workgroups per CU the register allocation is held to (2: two co-resident workgroups with half-depth rings -- one's
+// prologue / epilogue runs beside the other's K loop)
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN, int OCC = 1>
+__global__ __launch_bounds__(64 * (CM * CN + NP), OCC == 1 ? 1 : OCC * (CM * CN + NP) / 4) void gemm_ws_kernel(const GemmParams p) {      // (HIP: the second value is waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gemm_ws_body<T, BM, BN, CM, CN, S, NP, CONV, LN>(p, blockIdx.x, gridDim.x, smem);
 }
@@ -856,28 +858,31 @@ int gemm_ws_dual_launch(const GemmParams& a, const GemmParams& b, int dtype, hip
     return IMH_ERR_DTYPE;
 }
 
-template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN, int OCC = 1>
 static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 2 ? BM * 8 : (LN == 3 ? BN * 8 : 0));
-    auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN>;
+    auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN, OCC>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splits, 1), dim3(64 * (CM * CN + NP)), smem, stream, q);
     return check_launch("gemm_ws_kernel");
 }
 
-template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV>
+template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int OCC = 1>
 static int launch_ws(const GemmParams& p, hipStream_t stream) {
     if constexpr (!CONV) {
-        if ((p.flags & GF_LN_ROW) && p.ln_stats) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 2>(p, stream);
+        if ((p.flags & GF_LN_ROW) && p.ln_stats) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 2, OCC>(p, stream);
     }
-    if constexpr (!CONV && NP >= 3) {
+    if constexpr (!CONV && NP >= 3 && OCC == 1) {
         if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1>(p, stream);
     }
-    return launch_ws_ln<T, BM, BN, CM, CN, S, NP, CONV, 0>(p, stream);
+    if constexpr (OCC != 1) {
+        if (p.flags & GF_LN_ROW) { set_error("gemm_ws: the two-per-CU variants take the folded LayerNorm with precomputed statistics only"); return IMH_ERR_ARG; }
+    }
+    return launch_ws_ln<T, BM, BN, CM, CN, S, NP, CONV, 0, OCC>(p, stream);
 }
 
 template <typename T, int BM, int BN, bool CONV>
@@ -931,6 +936,8 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     if (bm == 2464 && bn == 160) return launch_ws<T, 64, 160, 2, 2, 4, 4, CONV>(p, stream);   // four producer waves
     if (bm == 24128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 4, 4, CONV>(p, stream);  // M = 8192, N = 640: 256 tiles
     if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 2, 2, 4, 4, CONV>(p, stream);
+    // 128 x 160 with a two-slot ring (74 KB) and 128 registers: TWO workgroups per CU, out of phase with each other
+    if (bm == 22128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 2, 2, CONV, 2>(p, stream);
     // 256 x 160, eight consumer waves (4 x 2, 64 x 80 each) + four producers, 3 stages (156 KB): N = 10240 -> 512 tiles
     if (bm == 23256 && bn == 160) return launch_ws<T, 256, 160, 4, 2, 3, 4, CONV>(p, stream);
     if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);

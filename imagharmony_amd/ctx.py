@@ -155,7 +155,7 @@ class Ctx:
     # ------------------------------------------------------------------ GEMM / conv
     # variant codes (include/imh.h): what each family can do, so that a tuning-table entry (keyed by shape only) is never
     # handed a launch it rejects
-    _WS = (1464, 2464, 24128, 23256)          # wave-specialised (gemm_ring.hip)
+    _WS = (1464, 2464, 24128, 23256, 22128)   # wave-specialised (gemm_ring.hip); 22128: two workgroups per CU
     _PP = (8256, 9128, 9256)                  # ping-pong (gemm_pp.hip)
     _HALO = (7128, 7564, 7328, 7428, 7256, 7356)   # LDS-halo conv3x3, stride 1 (7328 / 7428: weight rings; 7256 / 7356: 16 x 16 patch)
 

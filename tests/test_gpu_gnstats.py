@@ -57,7 +57,7 @@ def _check_groupnorm(ctx, y, B, hw, gn, dtype, what):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg,rows", [((1464, 160, 1), 32), ((2464, 160, 1), 32), ((24128, 160, 1), 64), ((23256, 160, 1), 64)])
+@pytest.mark.parametrize("cfg,rows", [((1464, 160, 1), 32), ((2464, 160, 1), 32), ((24128, 160, 1), 64), ((23256, 160, 1), 64), ((22128, 160, 1), 64)])
 def test_gemm_epilogue_leaves_groupnorm_partials(L, dtype, cfg, rows):
     """proj_out (bias + residual) and a plain biased GEMM on the wave-specialised variants, 10 / 20 / 40 channels per group"""
     ctx = ctx_for(dtype)
@@ -128,7 +128,7 @@ def test_ws_conv_epilogue_and_fallbacks(L, dtype):
     bias = rnd(Cout, dtype=dtype, seed=3)
     res = (rnd(B * hw, Cout, dtype=dtype, seed=6) * 1.5 + 0.5).contiguous()
     conv = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(B * hw, Cout)
-    for cfg in ((2464, 160, 1), (24128, 160, 1), (23256, 160, 1)):
+    for cfg in ((2464, 160, 1), (24128, 160, 1), (23256, 160, 1), (22128, 160, 1)):
         y, gn = ctx.conv3x3(x, pack_conv(w4), bias=bias, residual=res, cfg=cfg, gn_groups=G)
         rows = ctx.lib.imh_gemm_gn_block_rows(cfg[0], cfg[1])
         assert gn is not None and gn[1] == hw // rows

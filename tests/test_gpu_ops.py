@@ -56,7 +56,7 @@ def test_gemm_plain(L, dtype, cfg, shape):
 # variant codes of the big-tile / ring / ping-pong kernels (gemm_ring.hip, gemm_pp.hip): (bm code, bn, splits)
 BIG_VARIANTS = [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3064, 64, 1), (4128, 64, 1), (5064, 64, 1), (4064, 64, 1),
                 (4064, 128, 1), (6128, 320, 1), (5258, 320, 1), (6064, 160, 1), (8256, 256, 1), (9128, 320, 1), (9256, 320, 1),
-                (1464, 160, 1), (2464, 160, 1), (2464, 160, 2), (24128, 160, 1), (24128, 128, 1), (23256, 160, 1)]
+                (1464, 160, 1), (2464, 160, 1), (2464, 160, 2), (24128, 160, 1), (24128, 128, 1), (23256, 160, 1), (22128, 160, 1)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -180,7 +180,7 @@ def test_gemm_vt_perm(L, dtype, cfg):
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=10, W=20, Cin=64, Cout=384, cfg=(7564, 320, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(1464, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(2464, 160, 1)),
                                   dict(B=1, H=24, W=24, Cin=64, Cout=160, stride=2, cfg=(2464, 160, 2)),
-                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(24128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(24128, 128, 1))])
+                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(24128, 160, 1)), dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(22128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(24128, 128, 1))])
 def test_conv3x3(L, dtype, case):
     ctx = ctx_for(dtype)
     B, H, W, Cin, Cout = case["B"], case["H"], case["W"], case["Cin"], case["Cout"]

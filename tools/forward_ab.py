@@ -59,6 +59,12 @@ CONFIGS = collections.OrderedDict([
     ("j_gn_off", dict(gn_stats=False)),
     ("j_gn_on", dict(gn_stats=True)),
     # session K (--stacked 4): the S = 4 table; GEGLU with handed-over statistics on 128 x 128 instead of 256 x 160 ws
+    # session L: 128 x 160 wave-specialised tiles at TWO workgroups per CU (22128: two-slot rings, 4 consumer + 2 producer waves)
+    ("l_base", dict()),
+    ("l_geglu", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1], "8192,5120,640,0,1": [22128, 160, 1]})),
+    ("l_geglu32", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1]})),
+    ("l_all", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1], "8192,5120,640,0,1": [22128, 160, 1], "8192,640,640,0": [22128, 160, 1],
+                           "8192,640,2560,0": [22128, 160, 1]})),
     ("k_s4", dict()),
     ("k_s4_geglu64_128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1]})),
     ("k_s4_geglu_both128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1], "8192,10240,1280,0,1": [128, 128, 1]})),
