@@ -20,6 +20,16 @@ def main():
         for name, n, s, a, mn, mx in rows:
             short = name if len(name) < 110 else name[:107] + "..."
             f.write(f"| `{short}` | {n} | {s / 1e6:.3f} | {a / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * s / tot:.2f} |\n")
+        # idle time between consecutive dispatches of the library's kernels inside back-to-back regions (graph replays of the
+        # forward: every kernel waits for its predecessor): gap = start[i + 1] - end[i], pairs further than 50 us apart are
+        # region boundaries (host work), not launch gaps
+        ks = c.execute("select start, end from kernels where name like '%imh%' order by start").fetchall()
+        gaps = sorted(max(0, ks[i + 1][0] - ks[i][1]) for i in range(len(ks) - 1) if ks[i + 1][0] - ks[i][1] < 50000)
+        if gaps:
+            busy = sum(e - s0 for s0, e in ks)
+            f.write(f"\nlaunch gaps between consecutive imh kernels (pairs < 50 us apart): {len(gaps)} pairs, total {sum(gaps) / 1e6:.2f} ms "
+                    f"= {100 * sum(gaps) / (busy + sum(gaps)):.1f} % of busy + gap time; median {gaps[len(gaps) // 2] / 1e3:.2f} us, "
+                    f"p10 {gaps[len(gaps) // 10] / 1e3:.2f} us, p90 {gaps[len(gaps) * 9 // 10] / 1e3:.2f} us\n")
     print(open(out).read()[:3000])
 
 
