@@ -65,6 +65,12 @@ CONFIGS = collections.OrderedDict([
     ("l_geglu32", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1]})),
     ("l_all", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1], "8192,5120,640,0,1": [22128, 160, 1], "8192,640,640,0": [22128, 160, 1],
                            "8192,640,2560,0": [22128, 160, 1]})),
+    # session M: XCD partition forced for every GEMM (imh_debug_set key 2: 2..5 = (8,1) (4,2) (2,4) (1,8); 0 = cost model)
+    ("m_auto", dict()),
+    ("m_xcd81", dict(xcd=2)),
+    ("m_xcd42", dict(xcd=3)),
+    ("m_xcd24", dict(xcd=4)),
+    ("m_xcd18", dict(xcd=5)),
     ("k_s4", dict()),
     ("k_s4_geglu64_128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1]})),
     ("k_s4_geglu_both128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1], "8192,10240,1280,0,1": [128, 128, 1]})),
@@ -92,6 +98,7 @@ def main():
         AP.DUAL_WS = bool(c.get("dual_ws", False))
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
+        lib.imh_debug_set(2, int(c.get("xcd", 0)))
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
@@ -108,6 +115,7 @@ def main():
             rec, c = plans[n]
             lib.imh_debug_set(3, int(c.get("xattn", 0)))
             lib.imh_debug_set(4, int(c.get("attn", 0)))
+            lib.imh_debug_set(2, int(c.get("xcd", 0)))
             ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
@@ -120,6 +128,7 @@ def main():
             res[n]["wall_ms"].append(e0.elapsed_time(e1) / 3)
     lib.imh_debug_set(3, 0)
     lib.imh_debug_set(4, 0)
+    lib.imh_debug_set(2, 0)
     out = {}
     for n in names:
         rec, c = plans[n]
