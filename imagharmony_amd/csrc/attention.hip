@@ -20,7 +20,9 @@
 namespace imh {
 
 int g_attn_force_nw = 0;   // retired tuning knob (imh_debug_set key 0): only the 4-wave workgroup is built
-int g_attn_mode = 0;       // imh_debug_set key 4: 0 auto, 1 in-order key loop (attn_core), 2 software-pipelined key loop (attn_core_pipe; one key set)
+int g_attn_mode = 0;       // imh_debug_set key 4: 0 auto, 1 in-order key loop (attn_core), 2 software-pipelined key loop (attn_core_pipe; one
+                           // key set) with the textbook running maximum, 3 the same with the deferred maximum (= auto where it applies)
+constexpr float ATT_DEFER_LOG2 = 8.0f;
 
 // NW waves per workgroup (32 queries each); the launcher uses NW = 4.
 // NPASS = 1: single key set (self-attention, text-only cross-attention): no second accumulator, lower register
@@ -291,12 +293,14 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     constexpr int nw = 4;
     const int items = ((p.Lq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
     dim3 grid(8 * ((items + 7) / 8));
-    if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
+    if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || g_attn_mode == 3 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
         const int lds = ATT_PIPE_STAGES * 2 * ATT_TILE_BYTES;
+        AttnParams q = p;
+        q.defer_log2 = g_attn_mode == 2 ? 0.0f : ATT_DEFER_LOG2;
         if (dtype == IMH_DT_BF16) { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<bf16_t>, lds);
-                                    hipLaunchKernelGGL((attn_pipe_kernel<bf16_t>), grid, dim3(256), lds, stream, p); }
+                                    hipLaunchKernelGGL((attn_pipe_kernel<bf16_t>), grid, dim3(256), lds, stream, q); }
         else { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<f16_t>, lds);
-               hipLaunchKernelGGL((attn_pipe_kernel<f16_t>), grid, dim3(256), lds, stream, p); }
+               hipLaunchKernelGGL((attn_pipe_kernel<f16_t>), grid, dim3(256), lds, stream, q); }
         return check_launch("attn_pipe_kernel");
     }
 #define IMH_ATT_LAUNCH(TT, NWV) do { if (p.K2) hipLaunchKernelGGL((attn_kernel<TT, NWV, 2>), grid, dim3(64 * NWV), 0, stream, p); \

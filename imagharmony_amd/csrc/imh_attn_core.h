@@ -409,8 +409,16 @@ __device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned cha
         mx = fmaxf(mx, st[1][15]);
         return xhalf_max(mx);
     };
+    // Deferred maximum (cdna_hip_programming.md T13): the running maximum -- and with it the O / l rescale, which has to wait for
+    // the PV MFMAs it multiplies -- moves only when some row's maximum grew by more than 2^defer in the exponent domain; until
+    // then P = exp2((S - m_old) c) <= 2^defer (256: exact range for bf16 / fp16 operands, fp32 sums).  The decision sits after
+    // ALL of tile t's PV MFMAs and before tile t + 1's P is exponentiated, so every term is scaled exactly once.
+    // defer = 0 is the textbook rule (rescale whenever a maximum moved).  (s_setprio 1 over phase A -- the other workgroup's wave
+    // on the SIMD is mostly in its VALU-dense phase B -- was measured too: 23.1 vs 24.4 us at L = 1024 but 132 vs 128 at L = 4096
+    // and 70 vs 63.5 at batch 8, and the two wave-uniform branches alone cost the loop 5 %; not kept.)
+    const float defer = p.defer_log2;
     auto rescale = [&](const float m_new) {
-        if (__any(m_new != m_run)) {
+        if (__any((m_new - m_run) * c > defer)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
 #pragma unroll

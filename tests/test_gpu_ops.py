@@ -218,11 +218,12 @@ def sdpa_ref(q, k, v, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192), (1, 3, 128), (2, 1, 320), (1, 2, 384), (1, 1, 448),
                                     (1, 1, 512), (1, 2, 4096)])
 def test_attention_self(L, dtype, mode, B, H, Lq):
-    """mode (imh_debug_set key 4): 1 = in-order key loop, 2 = software-pipelined key loop (every tail of its unrolled tile
+    """mode (imh_debug_set key 4): 1 = in-order key loop, 2 / 3 = software-pipelined key loop with the textbook / the deferred
+    running maximum (every tail of its unrolled tile
     loop: 1 .. 8, 16, 64 tiles; a key count that is not a multiple of 64 always takes the in-order kernel)"""
     assert L.load().imh_debug_set(4, mode) == 0
     try:
@@ -325,12 +326,41 @@ def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_st
     assert_close(out.view(B, Lq, C_), ref, dtype, f"fused cross attention B={B} H={H} Lq={Lq} nt={nt} nip={nip} ln={ln}", k=8.0)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_attention_spiked_scores(L, mode):
-    """forces the online-softmax rescale path: one key dominates late in the sequence (both key loops)"""
+    """forces the online-softmax rescale path: one key dominates late in the sequence (every key loop)"""
     assert L.load().imh_debug_set(4, mode) == 0
     try:
         _spiked_case(L)
+    finally:
+        L.load().imh_debug_set(4, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_attention_creeping_maximum(L, dtype, mode):
+    """the deferred running maximum (mode 3 = the default of the pipelined loop): every 64-key tile raises the row maxima by
+    ~3 in the exponent domain, below the 2^8 deferral threshold per tile but 45 in total -- the rescale must fire every third
+    tile or so, P stays <= 2^8, and the result matches the reference like the textbook rule does"""
+    assert L.load().imh_debug_set(4, mode) == 0
+    try:
+        ctx = ctx_for(dtype)
+        B, H, Lq = 2, 2, 1024
+        g = torch.Generator(device="cpu").manual_seed(5)
+        q = torch.randn(B, Lq, H, 64, generator=g)
+        k = torch.randn(B, Lq, H, 64, generator=g) * 0.2
+        # a common direction u: q . u ~ +8 for every query, k . u grows by 3 / (0.125 * 8 * log2(e)) per tile
+        u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+        q = q + 8.0 * u
+        ramp = (torch.arange(Lq) // 64).float() * (3.0 / (0.125 * 8.0 * 1.4427))
+        k = k + ramp[None, :, None, None] * u
+        qk = torch.cat([q.reshape(B * Lq, H * 64), k.reshape(B * Lq, H * 64)], 1).to(dtype).to(DEV)
+        v = rnd(B, Lq, H * 64, dtype=dtype, seed=2)
+        out = ctx.new(B * Lq, H * 64)
+        C_ = H * 64
+        ctx.attention(qk[:, :C_], qk[:, C_:], make_vt(v, Lq), out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125)
+        ref = sdpa_ref(qk[:, :C_].reshape(B, Lq, C_), qk[:, C_:].reshape(B, Lq, C_), v, H)
+        assert_close(out.view(B, Lq, C_), ref, dtype, f"creeping maximum mode {mode}", k=6.0)
     finally:
         L.load().imh_debug_set(4, 0)
 

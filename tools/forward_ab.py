@@ -71,6 +71,9 @@ CONFIGS = collections.OrderedDict([
     ("m_xcd42", dict(xcd=3)),
     ("m_xcd24", dict(xcd=4)),
     ("m_xcd18", dict(xcd=5)),
+    # session N: deferred running maximum in the pipelined attention key loop (attn = 3, the default) vs the textbook rule (2)
+    ("n_attn2", dict(attn=2)),
+    ("n_attn3", dict(attn=3)),
     ("k_s4", dict()),
     ("k_s4_geglu64_128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1]})),
     ("k_s4_geglu_both128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1], "8192,10240,1280,0,1": [128, 128, 1]})),
