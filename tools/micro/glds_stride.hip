@@ -14,35 +14,38 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 constexpr int ROWS = 224;          // 64 + 160: one K tile of the 64 x 160 workgroup = 28 wave-instructions
 constexpr int GROUPS = ROWS / 8;
 
-template <int D>
-__global__ __launch_bounds__(256) void k(const unsigned char* src, size_t rowstride, size_t tilestride, int ktiles, int iters) {
+// NWV loader waves per workgroup (4: the kernels' producer group; 7 / 14 / 28: more issuing waves, same bytes in flight per CU when
+// D is scaled down); stagger: workgroup b starts at K tile (b % stagger) -- CUs that share the panel are not on the same lines at
+// the same time
+template <int D, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k(const unsigned char* src, size_t rowstride, size_t tilestride, int ktiles, int iters, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* ldsw = smem + wave * D * 1024;
-    int g = wave, kt = 0;                                   // wave w takes row groups w, w + 4, ... of every K tile (7 each)
+    int g = wave, kt = stagger > 1 ? (int)(blockIdx.x % stagger) % ktiles : 0;      // wave w takes row groups w, w + NWV, ... of every K tile
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const unsigned char* p = src + ((size_t)(g * 8 + (lane >> 3))) * rowstride + (size_t)kt * tilestride + (lane & 7) * 16;
             glds16(p, ldsw + d * 1024);
-            g += 4;
+            g += NWV;
             if (g >= GROUPS) { g = wave; if (++kt == ktiles) kt = 0; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
-template <int D>
-double run(const unsigned char* src, size_t rowstride, size_t tilestride, int ktiles, int wgs, int iters) {
+template <int D, int NWV = 4>
+double run(const unsigned char* src, size_t rowstride, size_t tilestride, int ktiles, int wgs, int iters, int stagger = 1) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const size_t lds = 4 * D * 1024;
-    hipFuncSetAttribute((const void*)k<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    k<D><<<wgs, 256, lds>>>(src, rowstride, tilestride, ktiles, iters);
+    const size_t lds = (size_t)NWV * D * 1024;
+    hipFuncSetAttribute((const void*)k<D, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    k<D, NWV><<<wgs, 64 * NWV, lds>>>(src, rowstride, tilestride, ktiles, iters, stagger);
     hipEventRecord(e0);
-    k<D><<<wgs, 256, lds>>>(src, rowstride, tilestride, ktiles, iters);
+    k<D, NWV><<<wgs, 64 * NWV, lds>>>(src, rowstride, tilestride, ktiles, iters, stagger);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    return (double)wgs * 4 * iters * D * 1024.0 / (ms * 1e-3) / 1e9;
+    return (double)wgs * NWV * iters * D * 1024.0 / (ms * 1e-3) / 1e9;
 }
 
 int main() {
@@ -61,6 +64,15 @@ int main() {
             printf("%zu, %d, %d, %d, %.0f, %.1f, %.2f\n", rs, ktiles, wgpc, DD, a, a / 256, 128.0 / (a / 256 / 2.1)); } while (0)
             RUN(7); RUN(14); RUN(21);
         }
+    }
+    // second table: more issuing waves in ONE workgroup per CU (bytes in flight per CU held at 84-112 KB), and a K stagger between workgroups
+    printf("\nrowstride_bytes, waves_per_wg, D, stagger_tiles, GBps_aggregate, GBps_per_cu\n");
+    {
+        const size_t rs = 10240, ts = 128; const int ktiles = 20, wgs = 256;
+#define RUNW(DD, NW, ST) do { const int iters = 16800 / (DD * NW); double a = run<DD, NW>(buf, rs, ts, ktiles, wgs, iters, ST); \
+        printf("%zu, %d, %d, %d, %.0f, %.1f\n", rs, NW, DD, ST, a, a / 256); } while (0)
+        RUNW(21, 4, 1); RUNW(21, 4, 2); RUNW(21, 4, 4); RUNW(21, 4, 8); RUNW(21, 4, 20);
+        RUNW(12, 7, 1); RUNW(6, 14, 1); RUNW(3, 28, 1); RUNW(12, 7, 4); RUNW(6, 14, 4);
     }
     return 0;
 }
