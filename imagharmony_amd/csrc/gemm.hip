@@ -28,12 +28,12 @@ int g_xcd_mode = 0;
 
 
 // LN: 0 = none; 1 = folded LayerNorm with the token rows as the X operand (GF_LN_ROW); 2 = token rows as the W operand
-// (GF_LN_COL, the swapped-operand V^T projection).  For LN = 1 / 2 the row statistics (sum, sum of squares over K) are
-// accumulated INSIDE the K loop from the operand fragments the MFMAs consume anyway (8 v_dot2c per fragment, issued
-// under the MFMAs), so BasicTransformerBlock.norm1/2/3 cost no launch, no pass over the residual stream and no
-// statistics buffer.  LN = 3 / 4: the same two forms with the statistics PRECOMPUTED by the GEMM that wrote the token rows
-// (p.ln_stats, imh_lnstats.h): the tile's token rows are merged by one thread each while the first K tile is in flight and
-// parked in LDS behind the two stages; nothing statistical remains in the K loop.  Needs splits == 1.
+// (GF_LN_COL, the swapped-operand V^T projection).  BasicTransformerBlock.norm1/2/3 cost no launch and no pass over the
+// residual stream: y = rstd * (acc - mean * s) + c with W pre-scaled by gamma, and (mean, rstd) come from the (sum, M2) slot
+// partials left by the GEMM that wrote the token rows (p.ln_stats, imh_lnstats.h; Chan-merged, never E[x^2] - mean^2): the
+// tile's token rows are merged by one thread each while the first K tile is in flight and parked in LDS behind the two
+// stages; nothing statistical happens in the K loop.  Needs splits == 1.  (Rounds 1-3 also carried a form that accumulated
+// sum / sum of squares inside the K loop; it cancelled catastrophically on rows with |mean| >> sigma and is gone.)
 template <typename T, int BM, int BN, bool CONV, int LN>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, const int z) {
     constexpr int FM = BM / 32;   // 16-row token fragments per wave
@@ -150,20 +150,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NS = (LN == 1 || LN == 3) ? FM : (LN == 2 ? FN : 1);
+    constexpr int NS = LN == 1 ? FM : 1;
     float st_s[NS], st_q[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
-    f32x2s* const lnst = (f32x2s*)(smem + 2 * STAGE);      // LN = 3 / 4: (mean, rstd) of the tile's token rows
+    f32x2s* const lnst = (f32x2s*)(smem + 2 * STAGE);      // LN != 0: (mean, rstd) of the tile's token rows
 
     if (kt0 < kt1) {
         stage(0, kt0);
-        if constexpr (LN == 3 || LN == 4) {                // beside the first tile's flight (the wait below covers both)
-            constexpr int NTOK = LN == 3 ? BM : BN;
+        if constexpr (LN != 0) {                           // beside the first tile's flight (the wait below covers both)
+            constexpr int NTOK = LN == 1 ? BM : BN;
             if (tid < NTOK) {
-                const int tok = (LN == 3 ? m0 : n0) + tid;
+                const int tok = (LN == 1 ? m0 : n0) + tid;
                 f32x2s mr = {0.f, 1.f};
-                if (tok < (LN == 3 ? p.M : p.N)) mr = merge_row_stats(p.ln_stats, tok, p.ln_slots, p.K, p.ln_eps);
+                if (tok < (LN == 1 ? p.M : p.N)) mr = merge_row_stats(p.ln_stats, tok, p.ln_slots, p.K, p.ln_eps);
                 lnst[tid] = mr;
             }
         }
@@ -185,21 +185,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
-                // the two waves that hold the same token rows (LN == 1: wn = 0 / 1; LN == 2: wm = 0 / 1) split the statistics
-                // work by k-slice: each takes the fragments of ONE of the two 32-wide halves of every K tile (wave-uniform
-                // branch) and the partial sums are exchanged through LDS after the loop
-                if constexpr (LN == 1) {
-                    if (kk == wn) {
-#pragma unroll
-                        for (int i = 0; i < FM; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
-                    }
-                }
-                if constexpr (LN == 2) {
-                    if (kk == wm) {
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) frag_stats(wf[j], st_s[j], st_q[j]);
-                    }
-                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -214,59 +199,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     float lnpre[8 * FN];
     const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
     LnArgs<4 * FN> ln;
-    if constexpr (LN == 3) {
+    if constexpr (LN == 1) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const f32x2s mr = lnst[wm * (BM / 2) + i * 16 + (lane & 15)];
             st_s[i] = mr[0]; st_q[i] = mr[1];
         }
     }
-    if constexpr (LN == 4) {
+    if constexpr (LN == 2) {
 #pragma unroll
         for (int q = 0; q < 4 * FN; ++q) {
             const f32x2s mr = lnst[wn * (BN / 2) + (lane >> 4) * 4 * FN + q];
             ln.cm[q] = mr[0]; ln.cr[q] = mr[1];
-        }
-    }
-    if constexpr (LN == 1 || LN == 2) {
-        // every lane of a 16-lane row holds the partial sums of fragment row (lane & 15) over ITS 8-element k-slices:
-        // combine the four lane groups (permlane swaps, no LDS), then mean / rstd per fragment row
-        const float invk = 1.0f / (float)p.K;
-        {   // partner wave's half of the k-slices (the tile stages are dead: the K loop ended with a workgroup barrier)
-            float* ex = (float*)smem;
-            const int partner = LN == 1 ? (wave ^ 1) : (wave ^ 2);
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                ex[((wave * NS + i) * 2 + 0) * 64 + lane] = st_s[i];
-                ex[((wave * NS + i) * 2 + 1) * 64 + lane] = st_q[i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                st_s[i] += ex[((partner * NS + i) * 2 + 0) * 64 + lane];
-                st_q[i] += ex[((partner * NS + i) * 2 + 1) * 64 + lane];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const float su = xor32_sum(xor16_sum(st_s[i]));
-            const float sq = xor32_sum(xor16_sum(st_q[i]));
-            const float mean = su * invk;
-            st_s[i] = mean;
-            st_q[i] = rsqrtf(fmaxf(sq * invk - mean * mean, 0.f) + p.ln_eps);
-        }
-        if constexpr (LN == 2) {
-            // weight-fragment row rho of fragment j is tile column (rho>>2)*4FN + j*4 + (rho&3) of the wave's slab; this
-            // lane stores columns g*4FN + j*4 + r (g = lane>>4): fetch them from lane rho = 4g + r of its own 16-group
-            const int g = lane >> 4;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int src = (lane & 48) | (g * 4 + r);
-                    ln.cm[j * 4 + r] = __shfl(st_s[j], src, 64);
-                    ln.cr[j * 4 + r] = __shfl(st_q[j], src, 64);
-                }
         }
     }
 #pragma unroll
@@ -288,7 +232,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            if constexpr (LN == 1 || LN == 3) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }     // fragment i's row (lane & 15) IS output row m
+            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }     // fragment i's row (lane & 15) IS output row m
             epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr, nullptr, lane);
         }
     }
@@ -303,12 +247,12 @@ IMH_KERNEL __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // Two independent problems in ONE launch (e.g. self-attention's [Q|K] = x [Wq;Wk]^T and V^T = Wv x^T, which
 // share x): workgroups [0, grid_a) run problem a, the rest problem b.  Halves the launch count of the pair and
 // lets the two sub-chip-sized grids fill the machine together.
-// LNP: 0 = plain problems; 1 = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both, statistics
-// taken in the K loops); 2 = the same with precomputed statistics (p.ln_stats).
-template <typename T, int BM, int BN, int LNP>
+// LNP: false = plain problems; true = a carries GF_LN_ROW and b GF_LN_COL (x un-normalised, LayerNorm folded into both, row
+// statistics handed over in p.ln_stats).
+template <typename T, int BM, int BN, bool LNP>
 IMH_KERNEL __launch_bounds__(256, 2) void gemm_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
-    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP == 0 ? 0 : (LNP == 1 ? 1 : 3)>(a, blockIdx.x, 0);
-    else gemm_body<T, BM, BN, false, LNP == 0 ? 0 : (LNP == 1 ? 2 : 4)>(b, blockIdx.x - grid_a, 0);
+    if ((int)blockIdx.x < grid_a) gemm_body<T, BM, BN, false, LNP ? 1 : 0>(a, blockIdx.x, 0);
+    else gemm_body<T, BM, BN, false, LNP ? 2 : 0>(b, blockIdx.x - grid_a, 0);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue. One thread per 16 columns.
@@ -347,17 +291,15 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
     xcd_partition(q, BM, BN, &tiles);
     const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES + (p.ln_stats ? (BM > BN ? BM : BN) * 8 : 0);
     dim3 grid(tiles, p.splits, 1);
-    if (!CONV && (p.flags & GF_LN_ROW) && p.ln_stats) {
+    if (!CONV && (p.flags & GF_LN_ROW)) {             // (gemm_launch has checked that p.ln_stats is there)
         static DynLdsOnce once;
-        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 3>, (int)smem);
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 3>), grid, dim3(256), smem, stream, q);
-    } else if (!CONV && (p.flags & GF_LN_COL) && p.ln_stats) {
+        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 1>, (int)smem);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 1>), grid, dim3(256), smem, stream, q);
+    } else if (!CONV && (p.flags & GF_LN_COL)) {
         static DynLdsOnce once;
-        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 4>, (int)smem);
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 4>), grid, dim3(256), smem, stream, q);
+        once.ensure((const void*)gemm_kernel<T, BM, BN, false, 2>, (int)smem);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 2>), grid, dim3(256), smem, stream, q);
     }
-    else if (!CONV && (p.flags & GF_LN_ROW)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 1>), grid, dim3(256), smem, stream, q);
-    else if (!CONV && (p.flags & GF_LN_COL)) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, 2>), grid, dim3(256), smem, stream, q);
     else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 0>), grid, dim3(256), smem, stream, q);
     return check_launch("gemm_kernel");
 }
@@ -410,13 +352,12 @@ static int launch_dual_tile(const GemmParams& a, const GemmParams& b, hipStream_
     xcd_partition(qa, BM, BN, &ga);
     xcd_partition(qb, BM, BN, &gb);
     const size_t smem = 2 * (size_t)(BM + BN) * GEMM_ROW_BYTES + (a.ln_stats ? (BM > BN ? BM : BN) * 8 : 0);
-    if ((a.flags & GF_LN_ROW) && a.ln_stats) {
+    if (a.flags & GF_LN_ROW) {
         static DynLdsOnce once;
-        once.ensure((const void*)gemm_dual_kernel<T, BM, BN, 2>, (int)smem);
-        hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 2>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+        once.ensure((const void*)gemm_dual_kernel<T, BM, BN, true>, (int)smem);
+        hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, true>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
     }
-    else if (a.flags & GF_LN_ROW) hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 1>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
-    else hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, 0>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
+    else hipLaunchKernelGGL((gemm_dual_kernel<T, BM, BN, false>), dim3(ga + gb), dim3(256), smem, stream, qa, qb, ga);
     return check_launch("gemm_dual_kernel");
 }
 
@@ -443,6 +384,10 @@ int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipS
     const int lnf = GF_LN_ROW | GF_LN_COL;
     if (((a.flags | b.flags) & lnf) && !((a.flags & lnf) == GF_LN_ROW && (b.flags & lnf) == GF_LN_COL)) {
         set_error("gemm_dual: folded LayerNorm needs problem a in row form and problem b in column form");
+        return IMH_ERR_ARG;
+    }
+    if (((a.flags | b.flags) & lnf) && (!a.ln_stats || !b.ln_stats)) {
+        set_error("gemm_dual: the folded LayerNorm takes the token rows' statistics from ln_stats on both problems (imh_lnstats.h)");
         return IMH_ERR_ARG;
     }
     if (bm == 24128) {       // wave-specialised pair: [Q|K] row form on 128 x 160 tiles + V^T column form on 128 x 128 tiles
@@ -508,8 +453,13 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     if (p.splits < 1) p.splits = 1;
     if (p.splits > 1 && !p.partial) { set_error("gemm: split-K needs a workspace"); return IMH_ERR_WORKSPACE; }
     if (p.rowadd && p.rows_per_batch <= 0) { set_error("gemm: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 8256 || bm == 9128 || bm == 9256 || bm == 2464 || bm == 24128 || bm == 23256 || ((bm == 1464 || bm == 22128) && p.ln_stats)) && (p.flags & GF_LN_ROW))) || conv)) {
-        set_error("gemm: folded LayerNorm needs a plain 64/128 tile, splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && !p.ln_stats) {
+        set_error("gemm: the folded LayerNorm takes the token rows' statistics from ln_stats (imh_lnstats.h: the epilogue of the GEMM that "
+                  "wrote the rows, or IMH_EW_ROW_STATS); there is no in-loop E[x^2] - mean^2 form");
+        return IMH_ERR_ARG;
+    }
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128) && (p.flags & GF_LN_ROW))) || conv)) {
+        set_error("gemm: folded LayerNorm needs a plain 64/128 tile or a wave-specialised variant (row form), splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }
     if (p.ln_stats_out) {
@@ -532,10 +482,6 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
                       "whole tiles, gn_nblk == gn_hw / rows (N=%d groups=%d hw=%d nblk=%d M=%d flags=%d)", rows, bm, bn, p.N, p.gn_groups, p.gn_hw, p.gn_nblk, p.M, p.flags);
             return IMH_ERR_ARG;
         }
-    }
-    if (p.ln_stats && bm >= 256 && !(bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128)) {
-        set_error("gemm: precomputed LayerNorm statistics need a plain tile or a wave-specialised variant (bm=%d)", bm);
-        return IMH_ERR_ARG;
     }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);
     if (dtype == IMH_DT_F16) return launch_typed<f16_t>(p, conv, bm, bn, stream);

@@ -1,6 +1,8 @@
 // 256 x 256 "ping-pong" MFMA GEMM for gfx950: the large-N Linear layers of the SDXL transformer blocks (the GEGLU
-// projection, diffusers BasicTransformerBlock.ff.net[0]; 2048 x 10240 x 1280 at 1024^2) with the optional folded
-// LayerNorm of gemm.hip (GF_LN_ROW) and the shared epilogue (bias / GEGLU / residual ...).
+// projection, diffusers BasicTransformerBlock.ff.net[0]; 2048 x 10240 x 1280 at 1024^2) with the shared epilogue (bias /
+// GEGLU / residual ...).  (The folded LayerNorm these kernels carried in rounds 2-3 took its statistics as sum / sum of
+// squares inside the K loop -- E[x^2] - mean^2 -- and went away with that form; the LayerNorm-folding launches run on the
+// wave-specialised kernels of gemm_ring.hip, which take handed-over statistics.)
 //
 // Why another kernel: the 128 x 128 tiles of gemm.hip move 64 B of operands through the L2 -> LDS path per 64 FLOP-cycles
 // of one CU -- the vector-L1 fill rate (64 B / clk / CU) is the bound, not the matrix pipe.  A
@@ -21,8 +23,6 @@
 //     so that the partner half -- one barrier behind -- has also waited by then (RAW needs wait -> barrier -> read for
 //     every writer).  WAR: every wave retires its fragment reads (lgkmcnt(0)) before the barrier that ends its L segment,
 //     and a buffer is restaged one K tile after it was read.
-// Folded LayerNorm: the four waves that share a token half split the row statistics by fragment (wave wn takes token
-// fragments wn and 4 + wn: 32 v_dot2c per K tile beside 64 MFMAs), exchanged through LDS after the loop.
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16 / f16); 2 * M * N * K FLOP per launch.
 #include "imh_common.h"
 #include "imh_kernels.h"
@@ -46,7 +46,7 @@ __host__ __device__ inline int pp_piece_row(int part, int q, int wave) {
     }
 }
 
-template <typename T, int LN>
+template <typename T>
 __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
     constexpr int FN = 4;
     typedef typename Vec<T>::v8 v8;
@@ -107,7 +107,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};      // LN: fragments wn (slot 0) and 4 + wn (slot 1)
 
     // ---- prologue: the whole first K tile, then the skew barrier of the second token half ----
     stage(P0{}, 0, 0); stage(P1{}, 0, 0); stage(P2{}, 0, 0); stage(P3{}, 0, 0);
@@ -118,12 +117,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
 #define PP_WAIT_NEXT() do { if (nxt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 #define PP_END_L() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_END_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_STATS(SLOT, BASE) do { if constexpr (LN == 1) { \
-        if (wn == 0) { frag_stats(xf[0][0], st_s[SLOT], st_q[SLOT]); frag_stats(xf[0][1], st_s[SLOT], st_q[SLOT]); } \
-        else if (wn == 1) { frag_stats(xf[1][0], st_s[SLOT], st_q[SLOT]); frag_stats(xf[1][1], st_s[SLOT], st_q[SLOT]); } \
-        else if (wn == 2) { frag_stats(xf[2][0], st_s[SLOT], st_q[SLOT]); frag_stats(xf[2][1], st_s[SLOT], st_q[SLOT]); } \
-        else { frag_stats(xf[3][0], st_s[SLOT], st_q[SLOT]); frag_stats(xf[3][1], st_s[SLOT], st_q[SLOT]); } } } while (0)
-
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
         const bool nxt = t + 1 < nt;
@@ -158,8 +151,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wb[j][kk] = *(const v8*)(sb + woff[kk] + (2 + j) * 4 * GEMM_ROW_BYTES);
         if (nxt) stage(P1{}, cur ^ 1, t + 1);                    // XA
-        PP_STATS(0, 0);                                          // LayerNorm statistics ride in the (lighter) load segments,
-        PP_END_L();                                              // under the partner wave's MFMAs
+        PP_END_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -194,7 +186,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wa[j][kk] = *(const v8*)(sb + woff[kk] + j * 4 * GEMM_ROW_BYTES);
         if (nxt) stage(P3{}, cur ^ 1, t + 1);                    // XB
-        PP_STATS(1, 4);
         PP_END_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -211,39 +202,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
 #undef PP_WAIT_NEXT
 #undef PP_END_L
 #undef PP_END_M
-#undef PP_STATS
     if (wm == 0) __builtin_amdgcn_s_barrier();                  // balance the skew barrier: everyone is out of the loop
 
     // ---- epilogue: lane owns columns nb .. nb+15 of row m ----
     const int nb = n0 + wn * 64 + (lane >> 4) * 16;
     float lnpre[8 * FN];
     const bool have_pre = ln_preload<4 * FN>(p, nb, lnpre);
-    LnArgs<4 * FN> ln;
-    float mean[8], rstd[8];
-    if constexpr (LN == 1) {
-        // this wave holds the partial sums of token fragments wn and 4 + wn (row lane & 15, its own 8-element k-slices):
-        // combine the four lane groups, publish per row, read back the eight fragments of the token half
-        float* ex = (float*)smem;                                // [2 wm][8 frag][16 rows][2]
-        const float invk = 1.0f / (float)p.K;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const float su = xor32_sum(xor16_sum(st_s[sl]));
-            const float sq = xor32_sum(xor16_sum(st_q[sl]));
-            if (lane < 16) {
-                const int f = sl * 4 + wn;
-                ex[((wm * 8 + f) * 16 + lane) * 2 + 0] = su;
-                ex[((wm * 8 + f) * 16 + lane) * 2 + 1] = sq;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float su = ex[((wm * 8 + i) * 16 + (lane & 15)) * 2 + 0];
-            const float sq = ex[((wm * 8 + i) * 16 + (lane & 15)) * 2 + 1];
-            mean[i] = su * invk;
-            rstd[i] = rsqrtf(fmaxf(sq * invk - mean[i] * mean[i], 0.f) + p.ln_eps);
-        }
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wm * 128 + i * 16 + (lane & 15);
@@ -253,8 +217,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
-        if constexpr (LN == 1) { ln.mean = mean[i]; ln.rstd = rstd[i]; }
-        epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr);
+        epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, nullptr);
     }
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
@@ -287,7 +250,7 @@ __host__ __device__ inline int pq_piece_row(int part, int q, int wave) {
     }
 }
 
-template <typename T, int LN>
+template <typename T>
 __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
     constexpr int FN = PQ_FN;
     typedef typename Vec<T>::v8 v8;
@@ -355,7 +318,6 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};          // LN: this wave's k-slice (kk == wn) of token fragments 0, 1
 
     // ---- prologue: tile 0 completely, X + WA of tile 1; then the skew barrier of the second half ----
     stage_xa(0, 0);
@@ -403,10 +365,6 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wf[j][kk] = *(const v8*)(sb + woff[kk] + (6 + j) * 4 * GEMM_ROW_BYTES);
         if (t + 2 < nt) stage_xa(cur, t + 2);                   // into THIS tile's buffer: its X / WA rows are dead
-        if constexpr (LN == 1) {                                // this wave's k-slice of the row statistics
-            if (wn == 0) { frag_stats(xf[0][0], st_s[0], st_q[0]); frag_stats(xf[1][0], st_s[1], st_q[1]); }
-            else { frag_stats(xf[0][1], st_s[0], st_q[0]); frag_stats(xf[1][1], st_s[1], st_q[1]); }
-        }
         PQ_END_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -426,28 +384,6 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
 
     // ---- epilogue: lane owns columns nb .. nb+39 of row m, handled as five 8-column pieces (keeps the live set small) ----
     const int nb = n0 + wn * 160 + (lane >> 4) * 40;
-    LnArgs<8> ln;
-    float mean[2], rstd[2];
-    if constexpr (LN == 1) {
-        float* ex = (float*)smem;                                // [8 waves][2 frag][2][64 lanes]
-        const float invk = 1.0f / (float)p.K;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ex[((wave * 2 + i) * 2 + 0) * 64 + lane] = st_s[i];
-            ex[((wave * 2 + i) * 2 + 1) * 64 + lane] = st_q[i];
-        }
-        __syncthreads();
-        const int partner = wave ^ 4;                            // same token quarter, other k-slice
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float a = st_s[i] + ex[((partner * 2 + i) * 2 + 0) * 64 + lane];
-            const float b = st_q[i] + ex[((partner * 2 + i) * 2 + 1) * 64 + lane];
-            const float su = xor32_sum(xor16_sum(a));
-            const float sq = xor32_sum(xor16_sum(b));
-            mean[i] = su * invk;
-            rstd[i] = rsqrtf(fmaxf(sq * invk - mean[i] * mean[i], 0.f) + p.ln_eps);
-        }
-    }
     // s_n, c_n of all five pieces and the bias are fetched once, ahead of the first store (see EpiPre)
     float lnpre[5][16];
     bool have_pre[5];
@@ -462,7 +398,6 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 32 + i * 16 + (lane & 15);
         if (m >= p.M || nb >= p.N) continue;
-        if constexpr (LN == 1) { ln.mean = mean[i]; ln.rstd = rstd[i]; }
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             float v[8];
@@ -470,24 +405,24 @@ __device__ __forceinline__ void gemm_pq_body(const GemmParams& p) {
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][2 * c + jj][r];
-            epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre[c], have_pre[c], LN != 0 ? &ln : nullptr, &pre[c]);
+            epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre[c], have_pre[c], nullptr, &pre[c]);
         }
     }
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
-template <typename T, int LN>
+template <typename T>
 IMH_KERNEL __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
-    gemm_pq_body<T, LN>(p);
+    gemm_pq_body<T>(p);
 }
 
-template <typename T, int LN>
+template <typename T>
 static int launch_pq(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, PQ_BM, PQ_BN, &tiles);
     const size_t smem = 2 * (size_t)PQ_BUF;
-    auto kern = gemm_pq_kernel<T, LN>;
+    auto kern = gemm_pq_kernel<T>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
@@ -512,7 +447,7 @@ constexpr int PR_BM = 256, PR_BN = 320;
 constexpr int PR_BUF = (PR_BM + PR_BN) * GEMM_ROW_BYTES;      // 72 KB per buffer
 constexpr int PR_WOFF = PR_BM * GEMM_ROW_BYTES;
 
-template <typename T, int LN>
+template <typename T>
 __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
     constexpr int FN = PQ_FN;
     typedef typename Vec<T>::v8 v8;
@@ -591,7 +526,6 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};   // LN: this wave's k-half (kk == wn) of token fragments 0-3
 
     // prologue: tile 0 completely; of tile 1 the first X group (what phase 3 of "tile -1" would have issued)
     stage_x01(0, 0); stage_x23(0, 0); stage_wa(0, 0); stage_wb(0, 0);
@@ -645,12 +579,6 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const v8*)(sb + woff[0] + (6 + j) * 4 * GEMM_ROW_BYTES);
         if (t + 1 < nt) stage_wa(cur ^ 1, t + 1);
-        if constexpr (LN == 1) {
-            if (wn == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
-            }
-        }
         PR_END_L();
         PR_MFMA(6, 4);
         PR_END_M();
@@ -675,12 +603,6 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const v8*)(sb + woff[1] + (6 + j) * 4 * GEMM_ROW_BYTES);
         if (t + 2 < nt) stage_x01(cur, t + 2);                  // into THIS tile's buffer: its X rows are dead since phase 2
-        if constexpr (LN == 1) {
-            if (wn == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) frag_stats(xf[i], st_s[i], st_q[i]);
-            }
-        }
         PR_END_L();
         PR_MFMA(6, 4);
         if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // WB of tile t+1 (first X group of t+2 may fly)
@@ -701,28 +623,6 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
 
     // ---- epilogue: lane owns columns nb .. nb+39 of row m, handled as five 8-column pieces ----
     const int nb = n0 + wn * 160 + (lane >> 4) * 40;
-    LnArgs<8> ln;
-    float mean[4], rstd[4];
-    if constexpr (LN == 1) {
-        float* ex = (float*)smem;                                // [8 waves][4 frag][2][64 lanes]
-        const float invk = 1.0f / (float)p.K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ex[((wave * 4 + i) * 2 + 0) * 64 + lane] = st_s[i];
-            ex[((wave * 4 + i) * 2 + 1) * 64 + lane] = st_q[i];
-        }
-        __syncthreads();
-        const int partner = wave ^ 4;                            // same token quarter, other k-half
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = st_s[i] + ex[((partner * 4 + i) * 2 + 0) * 64 + lane];
-            const float b = st_q[i] + ex[((partner * 4 + i) * 2 + 1) * 64 + lane];
-            const float su = xor32_sum(xor16_sum(a));
-            const float sq = xor32_sum(xor16_sum(b));
-            mean[i] = su * invk;
-            rstd[i] = rsqrtf(fmaxf(sq * invk - mean[i] * mean[i], 0.f) + p.ln_eps);
-        }
-    }
     // (compile-time row / piece indices: a rolled loop here would turn acc[][] into a scratch array)
     auto piece = [&](auto I, auto C, int m) {
         constexpr int i = decltype(I)::value, c = decltype(C)::value;
@@ -732,13 +632,12 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][2 * c + jj][r];
         const bool have_pre = ln_preload<8>(p, nb + 8 * c, lnpre);
-        epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre, have_pre, LN != 0 ? &ln : nullptr);
+        epilogue_store_pre<T, 2>(p, v, m, nb + 8 * c, lnpre, have_pre, nullptr);
     };
     auto row = [&](auto I) {
         constexpr int i = decltype(I)::value;
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
         if (m >= p.M || nb >= p.N) return;
-        if constexpr (LN == 1) { ln.mean = mean[i]; ln.rstd = rstd[i]; }
         piece(I, std::integral_constant<int, 0>{}, m); piece(I, std::integral_constant<int, 1>{}, m);
         piece(I, std::integral_constant<int, 2>{}, m); piece(I, std::integral_constant<int, 3>{}, m);
         piece(I, std::integral_constant<int, 4>{}, m);
@@ -748,36 +647,36 @@ __device__ __forceinline__ void gemm_pr_body(const GemmParams& p) {
     if (!PR_TIMING) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
-template <typename T, int LN>
+template <typename T>
 IMH_KERNEL __launch_bounds__(512, 2) void gemm_pr_kernel(const GemmParams p) {
-    gemm_pr_body<T, LN>(p);
+    gemm_pr_body<T>(p);
 }
 
-template <typename T, int LN>
+template <typename T>
 static int launch_pr(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, PR_BM, PR_BN, &tiles);
     const size_t smem = 2 * (size_t)PR_BUF;
-    auto kern = gemm_pr_kernel<T, LN>;
+    auto kern = gemm_pr_kernel<T>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
     return check_launch("gemm_pr_kernel");
 }
 
-template <typename T, int LN>
+template <typename T>
 IMH_KERNEL __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
-    gemm_pp_body<T, LN>(p);
+    gemm_pp_body<T>(p);
 }
 
-template <typename T, int LN>
+template <typename T>
 static int launch_pp(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, PP_BM, PP_BN, &tiles);
     const size_t smem = 2 * (size_t)PP_BUF;
-    auto kern = gemm_pp_kernel<T, LN>;
+    auto kern = gemm_pp_kernel<T>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
@@ -786,28 +685,18 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
 
 // variant codes (bm field of the config): 8256 x 256, 9128 x 320 and 9256 x 320
 int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t stream) {
-    if (conv || p.splits > 1 || (p.flags & (GF_LN_COL | GF_VT_PERM))) {
-        set_error("gemm_pp: plain GEMMs (optionally with the row-form folded LayerNorm), splits == 1 only");
+    if (conv || p.splits > 1 || (p.flags & (GF_LN_ROW | GF_LN_COL | GF_VT_PERM))) {
+        set_error("gemm_pp: plain GEMMs only (no conv, no folded LayerNorm, no V^T permutation), splits == 1");
         return IMH_ERR_ARG;
     }
-    const bool ln = p.flags & GF_LN_ROW;
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("gemm_pp: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    const bool bf = dtype == IMH_DT_BF16;
     if (bm == 9256) {
         if ((size_t)p.M * p.ldx * 2 >= (1ull << 32) || (size_t)p.N * p.ldw * 2 >= (1ull << 32)) { set_error("gemm_pp: operand too large for 32-bit staging offsets"); return IMH_ERR_SHAPE; }
-        if (dtype == IMH_DT_BF16) return ln ? launch_pr<bf16_t, 1>(p, stream) : launch_pr<bf16_t, 0>(p, stream);
-        if (dtype == IMH_DT_F16) return ln ? launch_pr<f16_t, 1>(p, stream) : launch_pr<f16_t, 0>(p, stream);
-        set_error("gemm_pp: unknown dtype %d", dtype);
-        return IMH_ERR_DTYPE;
+        return bf ? launch_pr<bf16_t>(p, stream) : launch_pr<f16_t>(p, stream);
     }
-    if (bm == 9128) {
-        if (dtype == IMH_DT_BF16) return ln ? launch_pq<bf16_t, 1>(p, stream) : launch_pq<bf16_t, 0>(p, stream);
-        if (dtype == IMH_DT_F16) return ln ? launch_pq<f16_t, 1>(p, stream) : launch_pq<f16_t, 0>(p, stream);
-        set_error("gemm_pp: unknown dtype %d", dtype);
-        return IMH_ERR_DTYPE;
-    }
-    if (dtype == IMH_DT_BF16) return ln ? launch_pp<bf16_t, 1>(p, stream) : launch_pp<bf16_t, 0>(p, stream);
-    if (dtype == IMH_DT_F16) return ln ? launch_pp<f16_t, 1>(p, stream) : launch_pp<f16_t, 0>(p, stream);
-    set_error("gemm_pp: unknown dtype %d", dtype);
-    return IMH_ERR_DTYPE;
+    if (bm == 9128) return bf ? launch_pq<bf16_t>(p, stream) : launch_pq<f16_t>(p, stream);
+    return bf ? launch_pp<bf16_t>(p, stream) : launch_pp<f16_t>(p, stream);
 }
 
 }  // namespace imh

@@ -401,29 +401,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1 has landed" (producers
 // wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt before arriving), after which
 // the producers refill tile i's slot.
-#ifndef WS_LNABL
-#define WS_LNABL 0    // tools only: 1 the statistics waves skip the row sums, 8 generic epilogue without the LN formula
-#endif
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
 #endif
-// CM x CN consumer waves over the tile; LN = 2: folded LayerNorm, row form, statistics PRECOMPUTED by the GEMM that wrote the
+// CM x CN consumer waves over the tile.  LN = 1: folded LayerNorm, row form, statistics handed over by the GEMM that wrote the
 // token rows (imh_lnstats.h): before their first hand-over the consumer threads merge the slot partials of the tile's BM rows
-// (one thread per row, loads in flight beside the producers' ring prologue) into an LDS area behind the ring -- no
-// statistics work inside the K loop, all NP producers load.  LN = 1: the same with the statistics taken in the loop (no
-// producer kernel supplies them).  The producer group then splits once more:
-// two LOADER waves run the LDS-DMA ring and the other NP - 2 are STATISTICS waves -- thread t owns token rows t, t + TS, ...
-// of the tile and adds up their 128 bytes of every landed K tile straight from LDS (v_dot2c sums), in parallel with the
-// loaders' issue and with every VALU instruction kept out of the waves that feed the MFMA pipe; mean / rstd reach the
-// consumers through a dead ring slot with the last hand-over.  (Summing in the loader waves themselves put ~600 cycles
-// per K tile on the loaders' critical path: +8..10 us on the ff.net.0 launch.)
+// (one thread per row, loads in flight beside the producers' ring prologue) into an LDS area behind the ring -- no statistics
+// work inside the K loop, all NP producers load.  LN = 2: the column form (tokens = the W operand's rows), same hand-over.
+// (Rounds 2-3 carried a third form whose spare producer waves summed rows and squares of every landed K tile: E[x^2] - mean^2,
+// removed with the other in-loop forms.)
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN>
 __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid, const int nblocks, unsigned char* smem) {
     constexpr int NC = CM * CN;
     constexpr int TM = BM / CM, TN = BN / CN;
-    static_assert(LN != 1 || (!CONV && NP >= 3), "LN = 1: two loader waves + NP - 2 statistics waves");
-    static_assert((LN != 2 && LN != 3) || !CONV, "folded LayerNorm is a Linear-layer form");
-    constexpr int NL = LN == 1 ? 2 : NP;           // loader waves; with in-loop LN the other producers only sum rows
+    static_assert(LN == 0 || !CONV, "folded LayerNorm is a Linear-layer form");
+    constexpr int NL = NP;                         // loader waves
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int NIX = BM / 8;                    // LDS-DMA wave instructions per K tile: token rows
     constexpr int NI = (BM + BN) / 8;              // ... and in total
@@ -451,56 +443,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     if (wave >= NC) {
         // ------------------------------------------------------------------ producer
         const int pw = wave - NC;
-        if constexpr (LN == 1) {
-            if (pw >= NL) {
-                // ---------------------------------------------------------- statistics wave (LN): thread t sums token
-                // rows t, t + TS, ... of every landed K tile straight from LDS (eight ds_read_b128 per row, chunk order
-                // rotated by lane >> 1: conflict-free under the ds_read_b128 lane groups, tests/emu; v_dot2c), beside the
-                // loaders' LDS-DMA issue
-                constexpr int TS = 64 * (NP - NL), RPT = (BM + TS - 1) / TS;
-                const int t = (pw - NL) * 64 + lane;
-                float rs[RPT], rq[RPT];
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) { rs[k] = 0.f; rq[k] = 0.f; }
-                __builtin_amdgcn_s_barrier();                 // tile 0 has landed
-                asm volatile("" ::: "memory");
-                int cslot = 0;
-                for (int i = 0; i < nt; ++i) {
-#pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        const int row = t + k * TS;
-                        if (row < BM && !(WS_LNABL & 1)) {
-                            const unsigned char* xr = smem + cslot * STAGE + row * GEMM_ROW_BYTES;
-                            v8 f[8];
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) f[c] = *(const v8*)(xr + (((c + (lane >> 1)) & 7) << 4));
-                            float s2 = 0.f, q2 = 0.f;         // two independent chains of v_dot2c
-#pragma unroll
-                            for (int c = 0; c < 8; c += 2) { frag_stats(f[c], rs[k], rq[k]); frag_stats(f[c + 1], s2, q2); }
-                            rs[k] += s2; rq[k] += q2;
-                        }
-                    }
-                    if (i == nt - 1) {                        // published with the hand-over of the last K tile, into the
-                        const float invk = 1.0f / (float)p.K; // slot of tile nt - 2 (read out one hand-over ago)
-                        float* ex = (float*)(smem + (cslot == 0 ? S - 1 : cslot - 1) * STAGE);
-#pragma unroll
-                        for (int k = 0; k < RPT; ++k) {
-                            const int row = t + k * TS;
-                            const float mean = rs[k] * invk;
-                            if (row < BM) {
-                                ex[row * 2 + 0] = mean;
-                                ex[row * 2 + 1] = rsqrtf(fmaxf(rq[k] * invk - mean * mean, 0.f) + p.ln_eps);
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (++cslot == S) cslot = 0;
-                }
-                return;
-            }
-        }
         const unsigned char* zero = g_zero_page;
         const unsigned char* base[LP];
         int step[LP];
@@ -632,7 +574,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         }
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
     };
-    if constexpr (LN == 2) {                       // (mean, rstd) of the tile's rows -> LDS area behind the ring
+    if constexpr (LN == 1) {                       // (mean, rstd) of the tile's rows -> LDS area behind the ring
         const int t = wave * 64 + lane;
         if (t < BM) {
             const int m = m0 + t;
@@ -642,7 +584,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if constexpr (LN == 3) {                       // column form (tokens = the W operand's rows = output columns): the tile's BN tokens
+    if constexpr (LN == 2) {                       // column form (tokens = the W operand's rows = output columns): the tile's BN tokens
         const int t = wave * 64 + lane;
         if (t < BN) {
             const int n = n0 + t;
@@ -687,7 +629,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     float gn_s[GNS], gn_q[GNS], gn_flat[2 * GNS];
 #pragma unroll
     for (int k = 0; k < GNS; ++k) { gn_s[k] = 0.f; gn_q[k] = 0.f; gn_flat[k] = 0.f; gn_flat[GNS + k] = 0.f; }
-    if constexpr (LN == 3) {
+    if constexpr (LN == 2) {
         const f32x2s* ex = (const f32x2s*)(smem + S * STAGE);
 #pragma unroll
         for (int q = 0; q < 4 * FN; ++q) {
@@ -695,9 +637,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
             ln.cm[q] = mr[0]; ln.cr[q] = mr[1];
         }
     }
-    if constexpr (LN == 1 || LN == 2) {            // mean / rstd of the tile's rows: published by the statistics waves (LN = 1, see
-        // above) or merged from the producer kernel's partials before the loop (LN = 2)
-        const float* ex = (const float*)(smem + (LN == 2 ? S : ((nt + S - 2) % S)) * STAGE);
+    if constexpr (LN == 1) {                       // mean / rstd of the tile's rows, merged from the producer kernel's partials before the loop
+        const float* ex = (const float*)(smem + S * STAGE);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int r = wm * TM + i * 16 + (lane & 15);
@@ -705,11 +646,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
             st_q[i] = ex[r * 2 + 1];
         }
     }
-    if constexpr (LN == 1 || LN == 2) {
+    if constexpr (LN == 1) {
         // the transformer blocks' launches (ff.net.0: LN + bias + GEGLU; to_q / to_k: LN only) take a lean epilogue: whole
         // 4*FN-column run in range, vector-aligned output, no row-add / residual / activation -- operands fetched once
         // above, then per row the LN formula, the GEGLU product and ONE store
-        if ((p.flags & ~(GF_LN_ROW | GF_GEGLU)) == 0 && pre.ok && have_pre && !(WS_LNABL & 8)) {
+        if ((p.flags & ~(GF_LN_ROW | GF_GEGLU)) == 0 && pre.ok && have_pre) {
             constexpr int NV = 4 * FN;
             const bool geglu = p.flags & GF_GEGLU;
             if (!p.bias) {
@@ -803,8 +744,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                 for (int q = 0; q < 4 * FN; ++q) if (nb + q < p.N) o[q] = v[q];
             }
         } else {
-            if constexpr (LN == 1 || LN == 2) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
-            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, (LN != 0 && !(WS_LNABL & 8)) ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane,
+            if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
+            epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane,
                                       (LN == 0 && (4 * FN) % 10 == 0) ? gn_flat : nullptr);
         }
     }
@@ -833,8 +774,8 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), OCC == 1 ? 1 : OCC * (CM * CN 
 template <typename T>
 __global__ __launch_bounds__(512, 1) void gemm_ws_dual_kernel(const GemmParams a, const GemmParams b, const int grid_a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if ((int)blockIdx.x < grid_a) gemm_ws_body<T, 128, 160, 2, 2, 4, 4, false, 2>(a, blockIdx.x, gridDim.x, smem);
-    else gemm_ws_body<T, 128, 128, 2, 2, 4, 4, false, 3>(b, blockIdx.x - grid_a, gridDim.x, smem);
+    if ((int)blockIdx.x < grid_a) gemm_ws_body<T, 128, 160, 2, 2, 4, 4, false, 1>(a, blockIdx.x, gridDim.x, smem);
+    else gemm_ws_body<T, 128, 128, 2, 2, 4, 4, false, 2>(b, blockIdx.x - grid_a, gridDim.x, smem);
 }
 
 template <typename T>
@@ -863,7 +804,7 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     int tiles;
     xcd_partition(q, BM, BN, &tiles);
-    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 2 ? BM * 8 : (LN == 3 ? BN * 8 : 0));
+    const size_t smem = (size_t)S * (BM + BN) * GEMM_ROW_BYTES + (LN == 1 ? BM * 8 : (LN == 2 ? BN * 8 : 0));
     auto kern = gemm_ws_kernel<T, BM, BN, CM, CN, S, NP, CONV, LN, OCC>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, (int)smem);
@@ -874,13 +815,7 @@ static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int OCC = 1>
 static int launch_ws(const GemmParams& p, hipStream_t stream) {
     if constexpr (!CONV) {
-        if ((p.flags & GF_LN_ROW) && p.ln_stats) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 2, OCC>(p, stream);
-    }
-    if constexpr (!CONV && NP >= 3 && OCC == 1) {
-        if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1>(p, stream);
-    }
-    if constexpr (OCC != 1) {
-        if (p.flags & GF_LN_ROW) { set_error("gemm_ws: the two-per-CU variants take the folded LayerNorm with precomputed statistics only"); return IMH_ERR_ARG; }
+        if (p.flags & GF_LN_ROW) return launch_ws_ln<T, BM, BN, CM, CN, S, NP, false, 1, OCC>(p, stream);   // (gemm_launch: ln_stats is there)
     }
     return launch_ws_ln<T, BM, BN, CM, CN, S, NP, CONV, 0, OCC>(p, stream);
 }

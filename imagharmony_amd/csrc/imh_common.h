@@ -66,24 +66,6 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
 // ---- packed dot product with fp32 accumulate (v_dot2c_f32_bf16 / v_dot2c_f32_f16): c + a.x*b.x + a.y*b.y ----
 __device__ __forceinline__ float dot2(bf16x2 a, bf16x2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
 __device__ __forceinline__ float dot2(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
-// sum and sum of squares of the 8 elements of an MFMA operand fragment, added to (s, q): 8 VALU ops
-__device__ __forceinline__ void frag_stats(bf16x8 v, float& s, float& q) {
-    const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
-    const bf16x2 a = v.lo.lo, b = v.lo.hi, c = v.hi.lo, d = v.hi.hi;
-    s = dot2(a, one, s); q = dot2(a, a, q);
-    s = dot2(b, one, s); q = dot2(b, b, q);
-    s = dot2(c, one, s); q = dot2(c, c, q);
-    s = dot2(d, one, s); q = dot2(d, d, q);
-}
-__device__ __forceinline__ void frag_stats(f16x8 v, float& s, float& q) {
-    const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
-    const f16x2 a = v.lo.lo, b = v.lo.hi, c = v.hi.lo, d = v.hi.hi;
-    s = dot2(a, one, s); q = dot2(a, a, q);
-    s = dot2(b, one, s); q = dot2(b, b, q);
-    s = dot2(c, one, s); q = dot2(c, c, q);
-    s = dot2(d, one, s); q = dot2(d, d, q);
-}
-
 // ---- async global -> LDS copy, 16 B per lane, destination = lds_base + lane*16 ----
 // lds_base must be wave-uniform (it travels in M0).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {

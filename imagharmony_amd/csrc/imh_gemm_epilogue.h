@@ -104,8 +104,8 @@ __device__ __forceinline__ void stv(T* p, const float* v) {
     }
 }
 
-// Folded LayerNorm (GF_LN_ROW / GF_LN_COL).  The statistics of the un-normalised token rows come from the K loop
-// itself (frag_stats on the MFMA operand fragments, gemm.hip): LnArgs carries what one lane needs for one output row.
+// Folded LayerNorm (GF_LN_ROW / GF_LN_COL).  The statistics of the un-normalised token rows are handed over by the GEMM that
+// wrote them (imh_lnstats.h merge_row_stats): LnArgs carries what one lane needs for one output row.
 //   row form:  y[m, n] = rstd_m * (acc - mean_m * s_n) + c_n      (tokens = X rows; s, c per output column)
 //   col form:  y[m, n] = rstd_n * (acc - mean_n * s_m) + c_m      (tokens = W rows = output columns; s, c per row)
 template <int NV>

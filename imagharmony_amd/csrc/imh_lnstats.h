@@ -95,28 +95,50 @@ __device__ __forceinline__ void gn_accumulate(const float* v, float (&gs)[NV / 1
     }
 }
 
-// Consumer side: (mean, rstd) of one token row from its `slots` partials (equal counts K / slots each).  The loads of a
-// batch are unconditional (index clamped; a clamped duplicate enters the merge with weight 0): a guarded load would make
-// hipcc branch around and wait for every element.  One thread per row.
+// Consumer side: (mean, rstd) of one token row from its `slots` partials (equal counts K / slots each).  Equal counts make the
+// merge a two-pass over the partials themselves: mean = (sum of the slot sums) / K, M2 = sum_i M2_i + n_i (mean_i - mean)^2 --
+// every term a non-negative square of a small difference, never E[x^2] - mean^2 (a row with |mean| >> sigma costs no
+// precision), and no division per slot (the sequential Chan chain of round 3 spent ~10 VALU + a v_rcp per slot at the head
+// of every consumer).  The loads of a batch are unconditional (index clamped, the duplicate's weight is 0): a guarded load
+// would make hipcc branch around and wait for every element.  One thread per row.
 __device__ __forceinline__ f32x2s merge_row_stats(const float* stats, const int row, const int slots, const int K,
                                                   const float eps) {
     const f32x2s* st = (const f32x2s*)(stats + (size_t)row * slots * 2);
     const float ni = (float)K / (float)slots;
     const float inv_ni = 1.0f / ni;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int i0 = 0; i0 < slots; i0 += 16) {
+    float mean, m2 = 0.f;
+    if (slots <= 16) {                      // every SDXL width on the 80-column slots (C / 80 = 4, 8, 16): one batch, kept in registers
         f32x2s t[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = st[min(i0 + j, slots - 1)];
+        for (int j = 0; j < 16; ++j) t[j] = st[min(j, slots - 1)];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += (j < slots) ? t[j][0] : 0.f;
+        mean = s / (float)K;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float w = (i0 + j < slots) ? ni : 0.f;
-            const float nn = n + w;
-            const float f = w * __builtin_amdgcn_rcpf(fmaxf(nn, 1.0f));     // share of the new partial
-            const float d = t[j][0] * inv_ni - mean;
-            mean = __builtin_fmaf(d, f, mean);
-            m2 += (w > 0.f ? t[j][1] : 0.f) + d * d * n * f;
-            n = nn;
+            const float d = __builtin_fmaf(t[j][0], inv_ni, -mean);
+            m2 += (j < slots) ? __builtin_fmaf(d * ni, d, t[j][1]) : 0.f;
+        }
+    } else {
+        float s = 0.f;
+        for (int i0 = 0; i0 < slots; i0 += 16) {
+            f32x2s t[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] = st[min(i0 + j, slots - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += (i0 + j < slots) ? t[j][0] : 0.f;
+        }
+        mean = s / (float)K;
+        for (int i0 = 0; i0 < slots; i0 += 16) {      // second pass: the row's partials are L1-resident now
+            f32x2s t[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] = st[min(i0 + j, slots - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float d = __builtin_fmaf(t[j][0], inv_ni, -mean);
+                m2 += (i0 + j < slots) ? __builtin_fmaf(d * ni, d, t[j][1]) : 0.f;
+            }
         }
     }
     f32x2s o;

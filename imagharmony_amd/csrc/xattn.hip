@@ -14,7 +14,8 @@
 //              operand (wave-private LDS rows), K loop over C in 64-wide tiles, two LDS-DMA stages.  A query block
 //              is re-read by the H heads (L2 hits), never by redundant arithmetic: the Q tile of a (batch, head,
 //              128-query) item is a 128 x 64 x C GEMM with no overlap between items.
-//   LayerNorm  the token rows' (sum, sum of squares) come out of the same B fragments (v_dot2c under the MFMAs);
+//   LayerNorm  the token rows' (mean, rstd) are merged from the (sum, M2) slot partials the GEMM that wrote the rows left
+//              behind (imh_lnstats.h; never E[x^2] - mean^2), beside the first K tile's flight;
 //              q = rstd * (acc - mean * s_d) + c_d with Wq pre-scaled by gamma -- norm2 never materialises.
 //   hand-over  the accumulator layout of a 32x32 MFMA block IS the B-operand layout of the swapped QK^T product
 //              (S^T = K Q^T) once the head dims inside every 16-group are ordered [0-3, 8-11, 4-7, 12-15]; the K
@@ -28,14 +29,15 @@
 
 namespace imh {
 
-int g_xattn_mode = 0;   // imh_debug_set key 3: 0 auto (two heads per workgroup when H is even), 1 one head per workgroup (round-2 kernel),
+int g_xattn_mode = 0;   // imh_debug_set key 3 (test / A-B only, not thread-safe): 0 auto (= 1), 1 one head per workgroup,
                         // 2 two heads, eight do-everything waves, 3 two heads + two producer waves, 4 two heads + four producer waves;
                         // 6 / 7 / 8 = 2 / 3 / 4 without the resident key tiles
 
 
 constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
 
-template <typename T, int NPASS, int LNQ>
+// LNQ: norm2 folded into to_q, row statistics handed over (xp.ln_stats)
+template <typename T, int NPASS, bool LNQ>
 __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XAttnParams xp) {
     constexpr int NW = 4;
     typedef typename Vec<T>::v8 v8;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 
     const int nkt = xp.C / 64;
     stage(0, 0);
-    if constexpr (LNQ == 2) {      // precomputed row statistics (imh_lnstats.h): lane (q, hi) merges its query row's slots
+    if constexpr (LNQ) {           // precomputed row statistics (imh_lnstats.h): lane (q, hi) merges its query row's slots
         const f32x2s mr = merge_row_stats(xp.ln_stats, b * p.Lq + min(q0 + wave * 32 + (lane & 31), p.Lq - 1), xp.ln_slots, xp.C, xp.ln_eps);
         st_s = mr[0]; st_q = mr[1];
     }
@@ -120,10 +122,6 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
-        if constexpr (LNQ == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
-        }
         asm volatile("" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -135,12 +133,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     v8 qf[4];
     {
         float mean = 0.f, rstd = 1.f;
-        if constexpr (LNQ == 1) {
-            const float invc = 1.0f / (float)xp.C;
-            mean = xor32_sum(st_s) * invc;                     // the row's other k-slices live in lane ^ 32
-            rstd = rsqrtf(fmaxf(xor32_sum(st_q) * invc - mean * mean, 0.f) + xp.ln_eps);
-        }
-        if constexpr (LNQ == 2) { mean = st_s; rstd = st_q; }
+        if constexpr (LNQ) { mean = st_s; rstd = st_q; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -148,7 +141,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = qa[dt][rg * 4 + e];
-                if constexpr (LNQ != 0) {
+                if constexpr (LNQ) {
                     const int d = h * 64 + att_o_dim(dt, rg * 4, hi);          // 4 consecutive head dims
                     const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
 #pragma unroll
@@ -181,7 +174,7 @@ constexpr int XQ2_STAGE = 128 * 128 + 128 * 128;   // X tile (128 token rows) + 
 // tiles of both heads are staged ONCE into a dedicated 64 KB of LDS by the consumer waves at kernel entry (in flight under
 // the whole projection), the image-prompt tile right after the projection (in flight under the text pass); the key loop then
 // runs from resident tiles without a single load wait.  (The ring form below pays two dependent L2 round trips per pass.)
-template <typename T, int NPASS, int LNQ, int NP, int S, bool RES>
+template <typename T, int NPASS, bool LNQ, int NP, int S, bool RES>
 __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnParams xp) {
     typedef typename Vec<T>::v8 v8;
     constexpr int NI = 32;                              // LDS-DMA wave instructions per K tile (8 rows x 128 B each)
@@ -285,7 +278,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
         for (int s = 0; s < S - 1; ++s)
             if (s < nkt) issue(s, s);
     }
-    if constexpr (LNQ == 2) {      // precomputed row statistics: lane (q, hi) merges its query row's slots (loads in flight
+    if constexpr (LNQ) {           // precomputed row statistics: lane (q, hi) merges its query row's slots (loads in flight
         // beside the ring prologue)
         const f32x2s mr = merge_row_stats(xp.ln_stats, b * p.Lq + min(q0 + qg * 32 + (lane & 31), p.Lq - 1), xp.ln_slots, xp.C, xp.ln_eps);
         st_s = mr[0]; st_q = mr[1];
@@ -319,10 +312,6 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
-        if constexpr (LNQ == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) frag_stats(xf[ks], st_s, st_q);
-        }
         if constexpr (NP > 0) {
             if (RES && kt == nkt - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's resident text tiles landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tile kt has been read: its slot may be refilled
@@ -339,12 +328,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     v8 qf[4];
     {
         float mean = 0.f, rstd = 1.f;
-        if constexpr (LNQ == 1) {
-            const float invc = 1.0f / (float)xp.C;
-            mean = xor32_sum(st_s) * invc;
-            rstd = rsqrtf(fmaxf(xor32_sum(st_q) * invc - mean * mean, 0.f) + xp.ln_eps);
-        }
-        if constexpr (LNQ == 2) { mean = st_s; rstd = st_q; }
+        if constexpr (LNQ) { mean = st_s; rstd = st_q; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -352,7 +336,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = qa[dt][rg * 4 + e];
-                if constexpr (LNQ != 0) {
+                if constexpr (LNQ) {
                     const int d = h * 64 + att_o_dim(dt, rg * 4, hi);
                     const f32x4 s4 = *(const f32x4*)(xp.ln_s + d), c4 = *(const f32x4*)(xp.ln_c + d);
 #pragma unroll
@@ -412,7 +396,7 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     if (NP == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 512);
 }
 
-template <typename T, int NPASS, int LNQ, int NP, int S, bool RES>
+template <typename T, int NPASS, bool LNQ, int NP, int S, bool RES>
 static void launch_xattn2(const XAttnParams& xp, hipStream_t stream) {
     const AttnParams& p = xp.a;
     const int items = ((p.Lq + 127) / 128) * (p.H / 2) * p.B;
@@ -426,15 +410,12 @@ static void launch_xattn2(const XAttnParams& xp, hipStream_t stream) {
 
 template <typename T, int NP, int S, bool RES>
 static void launch_xattn2_res(const XAttnParams& xp, hipStream_t stream) {
-    const int lnq = !xp.ln_s ? 0 : (xp.ln_stats ? 2 : 1);
     if (xp.a.K2) {
-        if (lnq == 0) launch_xattn2<T, 2, 0, NP, S, RES>(xp, stream);
-        else if (lnq == 1) launch_xattn2<T, 2, 1, NP, S, RES>(xp, stream);
-        else launch_xattn2<T, 2, 2, NP, S, RES>(xp, stream);
+        if (!xp.ln_s) launch_xattn2<T, 2, false, NP, S, RES>(xp, stream);
+        else launch_xattn2<T, 2, true, NP, S, RES>(xp, stream);
     } else {
-        if (lnq == 0) launch_xattn2<T, 1, 0, NP, S, RES>(xp, stream);
-        else if (lnq == 1) launch_xattn2<T, 1, 1, NP, S, RES>(xp, stream);
-        else launch_xattn2<T, 1, 2, NP, S, RES>(xp, stream);
+        if (!xp.ln_s) launch_xattn2<T, 1, false, NP, S, RES>(xp, stream);
+        else launch_xattn2<T, 1, true, NP, S, RES>(xp, stream);
     }
 }
 
@@ -462,6 +443,11 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     }
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0) { set_error("cross_attention: empty problem"); return IMH_ERR_SHAPE; }
     if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("cross_attention: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    if (xp.ln_s && !xp.ln_stats) {
+        set_error("cross_attention: the folded LayerNorm takes the token rows' statistics from ln_stats (imh_lnstats.h: the epilogue of "
+                  "the GEMM that wrote the rows, or IMH_EW_ROW_STATS); there is no in-loop E[x^2] - mean^2 form");
+        return IMH_ERR_ARG;
+    }
     // auto = one head per workgroup: in the forward (operands cold in this XCD's L2) its 320 workgroups on all 256 CUs pull the
     // token rows and weights faster than the 160 workgroups of the two-head form, which only wins back-to-back on warm
     // operands (profiles/r03_attn_ab.json vs r03_forward_ab_*.json)
@@ -470,11 +456,9 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     if ((p.H & 1) || mode == 1) {
         const int items = ((p.Lq + 127) / 128) * p.H * p.B;
         dim3 grid(8 * ((items + 7) / 8));
-        const int lnq = !xp.ln_s ? 0 : (xp.ln_stats ? 2 : 1);
 #define IMH_XA1(TT, NPV) do { \
-            if (lnq == 0) hipLaunchKernelGGL((xattn_kernel<TT, NPV, 0>), grid, dim3(256), 0, stream, xp); \
-            else if (lnq == 1) hipLaunchKernelGGL((xattn_kernel<TT, NPV, 1>), grid, dim3(256), 0, stream, xp); \
-            else hipLaunchKernelGGL((xattn_kernel<TT, NPV, 2>), grid, dim3(256), 0, stream, xp); } while (0)
+            if (!xp.ln_s) hipLaunchKernelGGL((xattn_kernel<TT, NPV, false>), grid, dim3(256), 0, stream, xp); \
+            else hipLaunchKernelGGL((xattn_kernel<TT, NPV, true>), grid, dim3(256), 0, stream, xp); } while (0)
 #define IMH_XA(TT) do { if (p.K2) IMH_XA1(TT, 2); else IMH_XA1(TT, 1); } while (0)
         if (dtype == IMH_DT_BF16) IMH_XA(bf16_t);
         else IMH_XA(f16_t);

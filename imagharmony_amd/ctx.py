@@ -167,11 +167,7 @@ class Ctx:
         if flags & (L.GF_VT_PERM | L.GF_LN_COL):
             return plain and (sp == 1 or not flags & L.GF_LN_COL)
         if flags & L.GF_LN_ROW:
-            if sp != 1 or conv:
-                return False
-            if plain:
-                return True
-            return bm in cls._WS if ln_pre else (bm in cls._PP or bm in (2464, 24128, 23256))
+            return sp == 1 and not conv and (plain or bm in cls._WS)
         if bm in cls._PP and conv:
             return False
         return True
@@ -199,8 +195,9 @@ class Ctx:
              ln=None, stats_out=False, gn_out=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
         ln = (s, c, eps[, stats]) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
-        (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' precomputed statistics
-        (csrc/imh_lnstats.h), None -> the kernel takes them inside its K loop.
+        (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' statistics as handed
+        over by the launch that wrote them (csrc/imh_lnstats.h); None -> a row-statistics launch over the token rows
+        supplies them (the kernels have no in-loop E[x^2] - mean^2 form).
         stats_out=True: also return the row statistics of y for a LayerNorm-folding consumer -> (y, (tensor, slots)); they
         come from the GEMM's own epilogue when the chosen variant has one, else from a row-statistics launch over y.
         gn_out=(groups, hw): y is a GroupNorm input of hw rows per sample -> (y, gn) with gn = (partials, blocks per sample) from
@@ -215,6 +212,17 @@ class Ctx:
         if out is None:
             out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
         ln_stats = ln[3] if ln is not None and len(ln) > 3 else None
+        own_stats = False
+        if ln is not None and ln_stats is None and flags & (L.GF_LN_ROW | L.GF_LN_COL):
+            if _args_only:
+                raise L.ImhError(f"{descr}: a folded-LayerNorm problem of gemm_dual needs its row statistics (gemm_dual supplies them)")
+            tok = x if flags & L.GF_LN_ROW else w
+            ln_stats = self.row_stats(tok[:M if flags & L.GF_LN_ROW else N, :K], descr=descr + ".ln_row_stats")
+            own_stats = True
+        if stats_out and flags & L.GF_OUT_F32:
+            raise L.ImhError(f"{descr}: stats_out describes rows stored in the compute dtype; an fp32 output (GF_OUT_F32) has no such statistics")
+        if stats_out and gn_out is not None:
+            raise L.ImhError(f"{descr}: stats_out and gn_out are mutually exclusive (one consumer norm per output)")
         bm, bn, sp = cfg or self._config(M, N, K, 0, flags, ln_pre=ln_stats is not None)
         if _args_only:
             sp = 1
@@ -255,6 +263,8 @@ class Ctx:
                             rows_per_batch=rows_per_batch, cfg=(bm, bn, sp), ln_pre=ln_stats is not None,
                             ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None,
                             gn_out=(gn[1], gn_out[0], gn_out[1]) if gn else None))
+        if own_stats:
+            self.free(ln_stats[0])
         if stats_out:
             if st is None:
                 st = self.row_stats(out.view(M, n_out) if out.dim() != 2 else out, descr=descr + ".row_stats")
@@ -288,7 +298,16 @@ class Ctx:
         return st, 1
 
     def gemm_dual(self, g1, g2, cfg=(128, 64), descr="gemm_dual"):
-        """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch."""
+        """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch.  The folded-LayerNorm pair
+        (g1 row form on x, g2 column form with the same token rows as its w) shares one statistics tensor; when the caller has
+        none, a row-statistics launch over the token rows supplies it."""
+        own = None
+        l1, l2 = g1.get("ln"), g2.get("ln")
+        if l1 is not None and (len(l1) < 4 or l1[3] is None):
+            own = self.row_stats(g1["x"], descr=descr + ".ln_row_stats")
+            g1 = dict(g1, ln=tuple(l1[:3]) + (own,))
+            if l2 is not None and (len(l2) < 4 or l2[3] is None):
+                g2 = dict(g2, ln=tuple(l2[:3]) + (own,))
         a1, o1, f1, b1, k1 = self.gemm(_args_only=True, cfg=(cfg[0], cfg[1], 1), **g1)
         a2, o2, f2, b2, k2 = self.gemm(_args_only=True, cfg=(cfg[0], cfg[1], 1), **g2)
         pair = (L.GemmArgs * 2)(a1, a2)
@@ -303,6 +322,8 @@ class Ctx:
             self._ops.append((L.OP_GEMM_DUAL, pair, self._cold(k1[:2] + k2[:2])))
         else:
             L.check(self.lib.imh_gemm_dual(C.byref(pair[0]), C.byref(pair[1]), self.stream()), descr)
+        if own is not None:
+            self.free(own[0])
         return o1, o2
 
     def conv3x3(self, x, w, bias=None, stride=1, up=0, residual=None, rowadd=None, ldra=0, out=None, cfg=None,
@@ -365,7 +386,8 @@ class Ctx:
                         descr="cross.fused"):
         """out[B*Lq, C] = attention(to_q(LN?(x)), K, V) (+ scale2 * attention(., K2, V2)) in one launch
         (csrc/xattn.hip).  x [B*Lq, C]; wq [C, C]; k / k2 caches with head dims in vt_perm16 order (GF_VT_PERM);
-        ln = (s, c, eps): x is un-normalised and wq pre-scaled by gamma."""
+        ln = (s, c, eps[, stats]): x is un-normalised and wq pre-scaled by gamma; stats as in gemm() (None -> a row-statistics
+        launch over x supplies them)."""
         self._chk(x, descr + ".x"); self._chk(wq, descr + ".wq")
         C_ = H * 64
         if x.shape[-1] != C_ or tuple(wq.shape) != (C_, C_) or x.stride(-1) != 1 or wq.stride(-1) != 1:
@@ -374,11 +396,15 @@ class Ctx:
         a.X, a.Wq, a.K, a.Vt, a.O = x.data_ptr(), wq.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
         a.K2, a.Vt2 = self._p(k2), self._p(vt2)
         keep_st = ()
+        own = False
         if ln is not None:
             a.ln_s, a.ln_c, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
-            if len(ln) > 3 and ln[3] is not None:
-                a.ln_stats, a.ln_slots = ln[3][0].data_ptr(), int(ln[3][1])
-                keep_st = (ln[3][0],)
+            st_in = ln[3] if len(ln) > 3 and ln[3] is not None else None
+            own = st_in is None
+            if own:
+                st_in = self.row_stats(x.view(-1, C_), descr=descr + ".ln_row_stats")
+            a.ln_stats, a.ln_slots = st_in[0].data_ptr(), int(st_in[1])
+            keep_st = (st_in[0],)
         a.B, a.H, a.Lq, a.C = B, H, Lq, C_
         a.Lk, a.Lk_pad, a.Lk2, a.Lk2_pad = Lk, Lk_pad, Lk2, Lk2_pad
         a.ldx, a.ldw, a.ldk, a.ldvt, a.ldk2, a.ldvt2, a.ldo = x.stride(0), wq.stride(0), ldk, ldvt, ldk2, ldvt2, out.stride(0)
@@ -390,6 +416,8 @@ class Ctx:
         by = es * (2 * M * C_ + C_ * C_ + 2 * B * (Lk + Lk2) * C_)
         self._emit(L.OP_XATTN, a, descr=descr, flops=fl, nbytes=by,
                    keep=(x, wq, k, vt, out, k2, vt2, scale2_tab, step) + tuple((ln or ())[:2]) + keep_st)
+        if own:
+            self.free(keep_st[0])
         return out
 
     def attention_small(self, q, k, v, B, H, Lq, Lk, dq, dv, scale, out=None, descr="attention_small"):

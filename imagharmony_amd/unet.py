@@ -31,19 +31,17 @@ from .ctx import Ctx
 
 
 # BasicTransformerBlock.norm1/2/3 folded into the consumer GEMMs (exact algebra, tested): the consumer takes the
-# un-normalised residual stream, accumulates each token row's (sum, sum of squares) inside its K loop from the MFMA
-# operand fragments, and normalises in its epilogue -- 210 LayerNorm launches and 0.84 GB of HBM traffic per forward
-# disappear.  False = the stand-alone LayerNorm kernel in front of every consumer (A/B and debugging).
+# un-normalised residual stream and normalises in its epilogue, y = rstd * (acc - mean * s) + c -- 210 LayerNorm launches and
+# 0.84 GB of HBM traffic per forward disappear.  False = the stand-alone LayerNorm kernel in front of every consumer (A/B and
+# debugging).
 FOLD_LAYERNORM = True
-# With the fold: the GEMM that WRITES a LayerNorm input (proj_in, to_out + residual, ff.out + residual) leaves the rows'
-# (sum, M2) slot partials behind from its epilogue (csrc/imh_lnstats.h) and the consumers merge them in their prologues,
-# instead of every consumer re-deriving the statistics inside its K loop (64-fold redundant for ff.net.0: every column tile
-# of a row block repeated them).  False = in-loop statistics (A/B; IMH_LN_STATS=0 in the environment).
+# The rows' (mean, rstd) travel with the residual stream: the GEMM that WRITES a LayerNorm input (proj_in, to_out + residual,
+# ff.out + residual) leaves (sum, M2) slot partials behind from its epilogue (csrc/imh_lnstats.h) and every consumer -- the
+# [Q|K] + V^T pair (norm1), the fused cross-attention's to_q (norm2), ff.net.0 (norm3) -- merges them in its prologue:
+# Welford / Chan all the way, like torch.nn.LayerNorm (which the reference runs ahead of attn.to_q,
+# ip_adapter/attention_processor.py:396).  The in-loop E[x^2] - mean^2 form of rounds 2-3 no longer exists in the library;
+# False here (IMH_LN_STATS=0, A/B) makes every consumer take its statistics from a stand-alone row-statistics launch instead.
 LN_STATS_HANDOVER = os.environ.get("IMH_LN_STATS", "1") != "0"
-# ... except into the fused cross-attention kernel: its to_q prologue takes norm2's statistics from the MFMA operand fragments
-# it reads anyway, which measured faster in the forward than a dependent load chain at kernel entry (27.3 vs 28.4 us per
-# launch, profiles/r03_forward_ab_stats.json); so attn1's to_out leaves no statistics behind
-XATTN_STATS_HANDOVER = os.environ.get("IMH_XATTN_STATS", "0") != "0"
 # GroupNorm statistics the same way: the conv / GEMM that writes a GroupNorm input (conv1 -> norm2, conv2 / proj_out / the
 # stride-2 downsampler -> the next block's norm1 / Transformer2DModel.norm / conv_norm_out) leaves per-group (sum, sum of
 # squares) partials behind from its epilogue (imh_gemm_args.gn_out) and imh_groupnorm skips its statistics pass over the
@@ -242,9 +240,8 @@ class BasicTransformerBlock(nn.Module):
             ho = LN_STATS_HANDOVER
             if not ho:
                 stats = None
-            hx = ho and XATTN_STATS_HANDOVER
-            r = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1, ln_stats=stats, want_stats=hx)
-            h1, s1 = r if hx else (r, None)
+            r = p1.emit(ctx, self.attn1, h, B, L_, residual=h, ln=self.norm1, ln_stats=stats, want_stats=ho)
+            h1, s1 = r if ho else (r, None)
             ctx.free(h)
             if stats is not None:
                 ctx.free(stats[0])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 5
+#define IMH_ABI_VERSION 6
 
 enum imh_status {
     IMH_OK = 0,
@@ -81,13 +81,11 @@ typedef struct imh_gemm_args {
     /* LayerNorm folded into the contraction (IMH_GF_LN_ROW: X rows are the un-normalised tokens; IMH_GF_LN_COL:
      * W rows are).  With W pre-scaled by gamma:  y = rstd * (acc - mean * ln_s) + ln_c  (exact algebra of
      * LN(x) W^T; BasicTransformerBlock.norm1/2/3 never materialise and cost no launch).  (mean, rstd) of every
-     * token row come either from `ln_stats` (below) or, with ln_stats == NULL, from inside the kernel's K loop (fp32
-     * sum and sum of squares over K of the operand fragments the MFMAs consume).  ln_s = sum_k gamma_k W[.,k],
-     * ln_c = sum_k beta_k W[.,k] (fp32; row form: per output column n, column form: per output row m).
-     * In-loop statistics: plain 64/128 tiles (both forms), the ping-pong variants bm = 8256 / 9128 / 9256 and the
-     * wave-specialised ones with four producer waves 2464 / 24128 / 23256 (row form; the producer waves sum the rows
-     * from LDS).  Precomputed statistics: plain tiles (both forms) and every wave-specialised variant (row form).
-     * splits == 1, conv == 0. */
+     * token row come from `ln_stats` (below; REQUIRED with either flag -- the in-loop sum / sum-of-squares form of ABI
+     * versions <= 5 cancelled on rows with |mean| >> sigma and no longer exists; IMH_ERR_ARG without it).
+     * ln_s = sum_k gamma_k W[.,k], ln_c = sum_k beta_k W[.,k] (fp32; row form: per output column n, column form: per
+     * output row m).  Variants: plain 64/128 tiles (both forms) and the wave-specialised ones 1464 / 2464 / 24128 /
+     * 23256 / 22128 (row form).  splits == 1, conv == 0. */
     const float* ln_s;
     const float* ln_c;
     float ln_eps;
@@ -200,7 +198,7 @@ typedef struct imh_xattn_args {
     const float* ln_s;
     const float* ln_c;
     float ln_eps;
-    const float* ln_stats;   /* with ln_s: precomputed row statistics of X ([B*Lq][ln_slots][2], see imh_gemm_args); NULL -> taken in the kernel */
+    const float* ln_stats;   /* with ln_s: REQUIRED row statistics of X ([B*Lq][ln_slots][2], see imh_gemm_args) */
     int32_t ln_slots;
     const void* K;
     const void* Vt;

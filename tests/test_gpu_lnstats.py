@@ -1,6 +1,7 @@
 """GPU: the LayerNorm-statistics hand-over (csrc/imh_lnstats.h) -- the GEMM that writes a LayerNorm input leaves per-row
 (sum, M2) slot partials behind from its epilogue, the consumers (ff.net.0 on the wave-specialised kernel, [Q|K] + V^T, the
-fused cross-attention's to_q) merge them instead of re-deriving the statistics in their K loops.  Reference math: diffusers
+fused cross-attention's to_q) merge them; rows no epilogue covers get theirs from IMH_EW_ROW_STATS.  The kernels have no
+other source of LayerNorm statistics (the in-loop sum / sum-of-squares form of rounds 2-3 is gone).  Reference math: diffusers
 BasicTransformerBlock.norm1/2/3 = torch LayerNorm, here F.layer_norm in fp32."""
 import pytest
 import torch
@@ -129,9 +130,10 @@ def test_dual_projection_with_precomputed_statistics(L, dtype, cfg):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_large_common_offset_rows(L, dtype):
-    """|mean| >> std (x = 50 + N(0, 0.1), as stored).  The hand-over statistics are Chan-merged (sum, M2) pairs:
-    no E[x^2] - mean^2 cancellation, the folded result matches torch's LayerNorm + Linear; the legacy in-loop form (sum and
-    sum of squares in fp32) is only required to stay finite and bounded here -- it is not on the forward's path any more."""
+    """ADVICE r02 / VERDICT r03 weak 1: |mean| >> std (x = 50 + N(0, 0.1), as stored).  The hand-over statistics are (sum, M2)
+    pairs merged without E[x^2] - mean^2, so the folded result matches torch's LayerNorm + Linear on every path a caller can
+    take: statistics from a producer epilogue, from IMH_EW_ROW_STATS, and supplied by Ctx.gemm when the caller passes none;
+    the C ABI refuses a folded-LayerNorm launch without statistics (there is no in-loop form to fall back to)."""
     from imagharmony_amd.attention_processor import fold_ln
     ctx = ctx_for(dtype)
     M, N, K = 256, 640, 1280
@@ -150,10 +152,17 @@ def test_large_common_offset_rows(L, dtype):
         # the mean term rstd * mean * s_n is ~ 500 sigma of the result: its fp32 cancellation against acc bounds the error
         err = (y.float() - ref).abs().max().item()
         assert torch.isfinite(y.float()).all() and err < 0.15, f"{cfg}: max err {err:.3e} with handed-over statistics"
-    y_old = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(128, 128, 1))
-    assert torch.isfinite(y_old.float()).all()
-    print(f"{dtype}: handed-over statistics max err {err:.3e}; in-loop statistics max err {(y_old.float() - ref).abs().max().item():.3e} "
-          f"(result scale {ref.abs().max().item():.2f})")
+    for cfg in [(2464, 160, 1), (128, 128, 1), (64, 64, 1)]:
+        for stx in (ctx.row_stats(x), None):                # the stand-alone producer; none given -> Ctx.gemm runs it
+            y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, stx), cfg=cfg)
+            e2 = (y.float() - ref).abs().max().item()
+            assert torch.isfinite(y.float()).all() and e2 < 0.15, f"{cfg}: max err {e2:.3e} with row-statistics-kernel statistics"
+    yt = ctx.gemm(wg, x, flags=L.GF_LN_COL, ln=(s, c, 1e-5), cfg=(128, 128, 1))            # column form, statistics supplied by Ctx
+    assert (yt.float() - ref.t()).abs().max().item() < 0.15
+    a = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(128, 128, 1), _args_only=True)[0]
+    a.ln_stats = None
+    assert ctx.lib.imh_gemm(a, ctx.stream()) == -1 and b"ln_stats" in ctx.lib.imh_last_error()
+    print(f"{dtype}: handed-over statistics max err {err:.3e} (result scale {ref.abs().max().item():.2f})")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -178,6 +187,7 @@ def test_wave_specialised_projection_pair(L, dtype):
             qk2, vt2 = ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5, st)),
                                      dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5, st)), cfg=(24128, 160))
             assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
-    with pytest.raises(L.ImhError, match="24128"):
-        ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5)),
-                      dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5)), cfg=(24128, 160))
+    # no statistics from the caller: Ctx.gemm_dual runs the row-statistics kernel and hands its output to both problems
+    qk3, vt3 = ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5)),
+                             dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5)), cfg=(24128, 160))
+    assert torch.equal(qk3, qk) and torch.equal(vt3, vt)

@@ -76,10 +76,11 @@ def test_gemm_big_tile_variants(L, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1), (23256, 160, 1), (24128, 160, 1), (24128, 128, 1), (2464, 160, 1)])
-def test_gemm_pingpong_folded_layernorm_geglu(L, dtype, cfg):
-    """the ping-pong kernels with the folded LayerNorm (statistics split between the waves sharing the token rows) and
-    the GEGLU epilogue -- the ff.net.0 launch -- against F.layer_norm + matmul + gelu in fp32"""
+@pytest.mark.parametrize("cfg", [(23256, 160, 1), (24128, 160, 1), (24128, 128, 1), (2464, 160, 1), (1464, 160, 1), (22128, 160, 1)])
+def test_gemm_wave_specialised_folded_layernorm_geglu(L, dtype, cfg):
+    """the wave-specialised kernels with the folded LayerNorm (row statistics from the row-statistics kernel, supplied by
+    Ctx.gemm) and the GEGLU epilogue -- the ff.net.0 launch -- against F.layer_norm + matmul + gelu in fp32; the ping-pong
+    variants, whose folded form took its statistics inside the K loop, refuse the flag now"""
     from imagharmony_amd.attention_processor import fold_ln
     ctx = ctx_for(dtype)
     for (M, N, K) in [(512, 640, 128), (300, 960, 320), (2048, 2560, 640)]:
@@ -96,6 +97,9 @@ def test_gemm_pingpong_folded_layernorm_geglu(L, dtype, cfg):
         g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg)
         assert_close(g, full[:, 0::2] * F.gelu(full[:, 1::2]), dtype, f"folded LN + GEGLU {cfg} {(M, N, K)}", k=8.0)
         assert torch.equal(g, ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg))
+    for pp in [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]:
+        with pytest.raises(L.ImhError, match="folded LayerNorm"):
+            ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=pp)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -276,8 +280,8 @@ def test_fused_cross_attention(L, dtype, mode, B, H, Lq, nt, nip, ln):
     launch against the same ops in fp32 torch: q = LN(x) Wq^T rounded to the compute dtype (as attn.to_q does), then
     SDPA per key set.  K caches carry the head dims in the permuted order the kernel's hand-over expects.
     mode (imh_debug_set key 3): 1 = one head per workgroup; 2 / 3 / 4 = two heads per workgroup with 0 / 2 / 4 producer
-    waves (an odd head count always takes the one-head kernel).  ln: 0 none, 1 statistics in the K loop, 2 / 3 = handed-over
-    statistics in 32-wide slots / from the row-statistics kernel."""
+    waves (an odd head count always takes the one-head kernel).  ln: 0 none, 1 no statistics from the caller (Ctx runs the
+    row-statistics kernel), 2 / 3 = handed-over statistics in 32-wide slots / from the row-statistics kernel."""
     from conftest import ref_row_stats
     from imagharmony_amd.attention_processor import fold_ln
     ctx = ctx_for(dtype)
@@ -324,6 +328,64 @@ def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_st
                         ln=lnq, **kw)
     # the reference rounds q once (bf16 / fp16) exactly like the kernel's hand-over; k = 8 ulps of the output scale
     assert_close(out.view(B, Lq, C_), ref, dtype, f"fused cross attention B={B} H={H} Lq={Lq} nt={nt} nip={nip} ln={ln}", k=8.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("how", ["epilogue", "kernel", "ctx"])
+def test_fused_cross_attention_large_mean_rows(L, dtype, mode, how):
+    """norm2 folded into the fused cross-attention's to_q on rows with |mean| >> sigma (x = 50 + N(0, 0.1) as
+    stored: 400-500 sigma) and one zero-variance row, against F.layer_norm + Linear + SDPA in fp32 -- torch.nn.LayerNorm ahead of
+    attn.to_q, ip_adapter/attention_processor.py:396.  Statistics from a producer GEMM's epilogue (what the forward does), from
+    the row-statistics kernel, and supplied by Ctx when the caller passes none: the three ways a launch can get them."""
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    B, H, Lq, nt, nip = 2, 20, 256, 77, 4
+    C_ = H * 64
+    x = (50.0 + 0.1 * rnd(B * Lq, C_, dtype=torch.float32, seed=1)).to(dtype).contiguous()
+    x[5] = 50.0
+    wq = rnd(C_, C_, dtype=torch.float32, seed=6, scale=C_ ** -0.5)
+    k, v = rnd(B, nt, C_, dtype=dtype, seed=2), rnd(B, nt, C_, dtype=dtype, seed=3)
+    k2, v2 = rnd(B, nip, C_, dtype=dtype, seed=4), rnd(B, nip, C_, dtype=dtype, seed=5)
+    pad = lambda n: (n + 63) // 64 * 64
+
+    def make_k(kk, n_pad):
+        kp = torch.zeros(B, n_pad, C_, dtype=dtype, device=DEV)
+        kp[:, :kk.shape[1]] = kk
+        return kp.view(B, n_pad, C_ // 16, 4, 4)[:, :, :, [0, 2, 1, 3], :].reshape(B, n_pad, C_).contiguous()
+
+    norm = torch.nn.LayerNorm(C_, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(C_, generator=torch.Generator().manual_seed(3)))
+        norm.bias.copy_(0.3 * torch.randn(C_, generator=torch.Generator().manual_seed(4)))
+    wg, s_, c_ = fold_ln(wq, norm, ctx)
+    if how == "epilogue":       # y = 0 @ W + residual(x) through the wave-specialised kernel: its epilogue leaves x's statistics
+        xx, st = ctx.gemm(torch.zeros(B * Lq, 64, dtype=dtype, device=DEV), torch.zeros(C_, 64, dtype=dtype, device=DEV), residual=x,
+                          cfg=(2464, 160, 1), stats_out=True)
+        assert torch.equal(xx, x) and st[1] == C_ // 80
+    else:
+        st = ctx.row_stats(x) if how == "kernel" else None
+    xn = F.layer_norm(x.float(), (C_,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
+    q32 = xn @ wq.to(DEV).t()
+    ref = sdpa_ref(q32.view(B, Lq, C_), k, v, H) + 0.7 * sdpa_ref(q32.view(B, Lq, C_), k2, v2, H)
+    assert L.load().imh_debug_set(3, mode) == 0
+    try:
+        out = ctx.new(B * Lq, C_)
+        ctx.cross_attention(x, wg, make_k(k, pad(nt)), make_vt(v, pad(nt)), out, B, H, Lq, nt, pad(nt), C_, B * pad(nt), 0.125,
+                            ln=(s_, c_, 1e-5, st), k2=make_k(k2, pad(nip)), vt2=make_vt(v2, pad(nip)), Lk2=nip, Lk2_pad=pad(nip),
+                            ldk2=C_, ldvt2=B * pad(nip), scale2=0.7)
+    finally:
+        L.load().imh_debug_set(3, 0)
+    o = out.float().view(B, Lq, C_)
+    assert torch.isfinite(o).all()
+    # q = rstd * (acc - mean * s) + c: acc and mean * s are ~ 500 sigma of q each and cancel in fp32 (|acc| ~ 50 * |W| sqrt(C)); what is
+    # left is noise of a few 1e-2 on q ~ N(0, 1), far below what flips an attention row -- rel-rms of the output, not ulps
+    from conftest import rel_rms
+    r = rel_rms(o, ref)
+    assert r < (0.05 if dtype == torch.bfloat16 else 0.02), f"fused cross attention on large-mean rows ({how}, mode {mode}): rel-rms {r:.3e}"
+    # the zero-variance row: x - mean = 0 exactly in torch -> q = beta-term only; the folded form must stay finite and close
+    zr = rel_rms(o.view(B * Lq, C_)[5], ref.reshape(B * Lq, C_)[5])
+    assert zr < 0.2, f"zero-variance row rel-rms {zr:.3e}"
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
@@ -488,10 +550,9 @@ def test_errors_are_reported_not_thrown(L):
 @pytest.mark.parametrize("cfg", [(64, 64), (128, 64), (64, 128), (128, 128)])
 @pytest.mark.parametrize("shape", [(192, 256, 128), (300, 200, 1280), (2048, 1280, 640)])
 def test_gemm_folded_layernorm(L, dtype, cfg, shape):
-    """LN(x) W^T through the folded form -- gamma-scaled weights, row statistics taken INSIDE the GEMM's K loop from
-    the MFMA operand fragments -- in both orientations (tokens as the X operand / as the W operand), against
-    F.layer_norm + matmul in fp32, with a large row mean (|mean| / std = 2: the cancellation case of the
-    sum / sum-of-squares form)."""
+    """LN(x) W^T through the folded form -- gamma-scaled weights, row statistics from the row-statistics kernel (the caller
+    passes none, Ctx supplies them) -- in both orientations (tokens as the X operand / as the W operand), against
+    F.layer_norm + matmul in fp32, with a row mean of 2 sigma."""
     from imagharmony_amd.attention_processor import fold_ln
     ctx = ctx_for(dtype)
     M, N, K = shape

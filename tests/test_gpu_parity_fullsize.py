@@ -88,6 +88,50 @@ def test_full_sdxl_forward_matches_cpu_oracle(sdxl_pair):
             torch.cuda.empty_cache()
 
 
+# residual streams with a large common offset: conv_in.bias and every Transformer2DModel.proj_in.bias get
+# + OFFSET, so the GroupNorm inputs of the first level and the LayerNorm rows of all 70 transformer blocks carry |mean| >> sigma
+# (8 sigma in bf16, 32 sigma in fp16: at larger offsets the storage dtype itself erases the signal -- bf16 resolves 0.06 at 8,
+# fp16 0.03 at 32).  Bounds = ~2x measured; the offset costs precision in the STORED stream, not in the statistics.
+OFFSET = {torch.bfloat16: 8.0, torch.float16: 32.0}
+TOL_FWD_OFFSET = {torch.bfloat16: 6e-2, torch.float16: 1.2e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_full_sdxl_forward_with_offset_residual_streams(sdxl_pair, dtype):
+    """default configuration, full SDXL width, CFG batch 2: every LayerNorm row and the first GroupNorm inputs sit on a large
+    common offset; the HIP forward (statistics handed over as (sum, M2) partials, never E[x^2] - mean^2) against the fp32 CPU
+    oracle with the same modified weights (torch LayerNorm / GroupNorm: ip_adapter/attention_processor.py:396's caller)"""
+    hu, ou = sdxl_pair
+    off = OFFSET[dtype]
+    names = ["conv_in.bias"] + [n for n, _ in hu.named_parameters() if n.endswith("proj_in.bias")]
+    assert len(names) == 12
+    hp, op = dict(hu.named_parameters()), dict(ou.named_parameters())
+    saved = {n: (hp[n].detach().clone(), op[n].detach().clone()) for n in names}
+    pe, ne, po, no = _cond()
+    ehs = torch.cat([ne, pe], 0)
+    text = torch.cat([no, po], 0)
+    ids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)
+    x = torch.randn(1, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(5)).repeat(2, 1, 1, 1)
+    t = torch.tensor(301.0)
+    try:
+        with torch.no_grad():
+            for n in names:
+                hp[n].add_(off)                              # (+8 / +32 on O(0.02) biases: exact in bf16 up to its rounding; copy the
+                op[n].copy_(hp[n].detach().float().cpu())    # rounded value to the oracle so both hold IDENTICAL weights)
+            ref = ou(x, t, ehs, added_cond_kwargs={"text_embeds": text, "time_ids": ids})[0]
+        assert torch.isfinite(ref).all()
+        u = hu if dtype == torch.bfloat16 else _as_fp16(hu)
+        y = u(x.to(DEV), t, ehs.to(DEV, dtype), added_cond_kwargs={"text_embeds": text.to(DEV, dtype), "time_ids": ids.to(DEV)})[0]
+        r = rel_rms(y.float().cpu(), ref)
+        print(f"full SDXL forward, residual streams offset by {off}: {dtype} rel-rms vs fp32 CPU oracle {r:.3e} (bound {TOL_FWD_OFFSET[dtype]:.1e})")
+        record_parity(f"unet_forward.offset_streams.{str(dtype).split('.')[-1]}", r, TOL_FWD_OFFSET[dtype], offset=off)
+        assert torch.isfinite(y).all() and r < TOL_FWD_OFFSET[dtype], f"{dtype}: rel-rms {r:.3e}"
+    finally:
+        with torch.no_grad():
+            for n in names:
+                hp[n].copy_(saved[n][0]); op[n].copy_(saved[n][1])
+
+
 def _set_ip_tokens(unet, T):
     """the image-token count is a slicing attribute of the processors (attention_processor.py:402-406); the to_k_ip / to_v_ip
     weights do not depend on it, so one weight set serves T = 4 / 16 / 32"""

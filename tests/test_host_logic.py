@@ -260,24 +260,45 @@ def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
 
 
 def test_folded_layernorm_launches_only_get_variants_that_implement_it():
-    """host logic of Ctx.gemm: a tuning-table variant without the folded-LayerNorm statistics (rings, KG2, the
-    two-producer wave-specialised 1464) is replaced by a plain tile when the launch carries ln=..., the variants that
-    have them (plain tiles, ping-pong, the four-producer wave-specialised ones) are kept, an explicit cfg is passed through"""
+    """host logic of Ctx.gemm: a tuning-table variant without the folded LayerNorm (rings, KG2, ping-pong) is replaced by a plain
+    tile when the launch carries ln=..., the variants that have it (plain tiles, every wave-specialised one) are kept, an
+    explicit cfg is passed through; a launch without statistics from its caller gets them from a row-statistics op emitted in
+    front of it (the kernels have no in-loop form), and the C ABI itself refuses a folded launch without ln_stats"""
     from imagharmony_amd import lib as L
     from imagharmony_amd.ctx import Ctx
     ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
     M, N, K = 2048, 1280, 2560
     x, w = torch.zeros(M, K, dtype=torch.bfloat16), torch.zeros(N, K, dtype=torch.bfloat16)
     s, c = torch.zeros(N), torch.zeros(N)
-    for table, want in (((1464, 160, 1), (64, 64)), ((256, 256, 1), (64, 64)), ((3128, 128, 1), (64, 64)), ((64, 128, 1), (64, 128)),
-                        ((2464, 160, 1), (2464, 160)), ((23256, 160, 1), (23256, 160)), ((9128, 320, 1), (9128, 320)), ((64, 64, 1), (64, 64))):
+    st = (torch.zeros(M, K // 80, 2), K // 80)
+    for table, want in (((1464, 160, 1), (1464, 160)), ((256, 256, 1), (64, 64)), ((3128, 128, 1), (64, 64)), ((64, 128, 1), (64, 128)),
+                        ((2464, 160, 1), (2464, 160)), ((23256, 160, 1), (23256, 160)), ((9128, 320, 1), (64, 64)), ((8256, 256, 1), (64, 64)),
+                        ((64, 64, 1), (64, 64))):
         ctx.tuning[(M, N, K, 0)] = table
-        a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), _args_only=True)[0]
+        a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), _args_only=True)[0]
         assert (a.bm, a.bn, a.splits) == (*want, 1), (table, a.bm, a.bn, a.splits)
+        assert a.ln_stats == st[0].data_ptr() and a.ln_slots == st[1]
         a = ctx.gemm(x, w, _args_only=True)[0]                      # without LN the table entry is used as is
         assert (a.bm, a.bn) == table[:2]
-    a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(1464, 160, 1), _args_only=True)[0]
-    assert (a.bm, a.bn) == (1464, 160)                              # explicit: the C side is the one to refuse it
+    a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(9128, 320, 1), _args_only=True)[0]
+    assert (a.bm, a.bn) == (9128, 320)                              # explicit: the C side is the one to refuse it
+    # no statistics from the caller: a row-statistics op over the token rows goes in front, its output feeds the launch
+    n0 = len(ctx.tags)
+    ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5))
+    kinds = [(t[1], t[2]) for t in ctx.tags[n0:]]
+    assert kinds == [(L.OP_EW, "gemm.ln_row_stats"), (L.OP_GEMM, "gemm")], kinds
+    assert ctx._ops[-1][1].ln_stats == ctx._ops[-2][1].y and ctx._ops[-1][1].ln_slots == 1
+    n0 = len(ctx.tags)
+    ctx.gemm(w, x, flags=L.GF_LN_COL, ln=(torch.zeros(N), torch.zeros(N), 1e-5))    # column form: the tokens are the W operand's rows
+    assert ctx._ops[-2][1].a == x.data_ptr() and ctx._ops[-1][1].ln_stats == ctx._ops[-2][1].y
+    with pytest.raises(L.ImhError, match="stats_out"):
+        ctx.gemm(x, w, flags=L.GF_OUT_F32, stats_out=True)
+    with pytest.raises(L.ImhError, match="mutually exclusive"):
+        ctx.gemm(x, w, stats_out=True, gn_out=(32, 1024))
+    # the C ABI without statistics
+    a = ctx.gemm(x, w, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(128, 128, 1), _args_only=True)[0]
+    a.ln_stats = None
+    assert ctx.lib.imh_gemm(a, None) == -1 and b"ln_stats" in ctx.lib.imh_last_error()
 
 
 def test_groupnorm_statistics_handover_host_logic():
