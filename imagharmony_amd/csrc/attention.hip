@@ -20,8 +20,9 @@
 namespace imh {
 
 int g_attn_force_nw = 0;   // retired tuning knob (imh_debug_set key 0): only the 4-wave workgroup is built
-int g_attn_mode = 0;       // imh_debug_set key 4: 0 auto, 1 in-order key loop (attn_core), 2 software-pipelined key loop (attn_core_pipe; one
-                           // key set) with the textbook running maximum, 3 the same with the deferred maximum (= auto where it applies)
+int g_attn_mode = 0;       // imh_debug_set key 4 (tests / A-B only; read at launch or capture time, not thread-safe): 0 auto, 1 in-order key loop
+                           // (attn_core), 2 software-pipelined key loop (attn_core_pipe; one key set) with the textbook running maximum, 3 the same
+                           // with the deferred maximum, 5 key-split workgroups (attn_ks_kernel, deferred maximum), 6 the same, textbook maximum
 constexpr float ATT_DEFER_LOG2 = 8.0f;
 
 // NW waves per workgroup (32 queries each); the launcher uses NW = 4.
@@ -123,6 +124,43 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
     attn_core_pipe<T>(p, smem, qf, b, h, wave, lane, fin);
     attn_store<T, NW>(p, qs, fin, b, h, q0, wave, lane);
     tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+}
+
+// Key-split self-attention (imh_attn_core.h attn_core_ks): one workgroup = (batch, head, 128 queries) = 8 waves = 2 key halves x 4
+// query groups; 128 registers and 64 KB of LDS -> two workgroups = four waves per SIMD on a CU.  Q fragments come straight from
+// memory (lane (q, hi) reads its row's four 16-B pieces: 32 lines per instruction, once per workgroup, in flight beside the
+// first K / V^T tile) -- no Q staging tile, no extra barrier.
+template <typename T>
+__global__ __launch_bounds__(512, 4) void attn_ks_kernel(const AttnParams p) {
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 groups x 2 slots x (K + V^T tile) = 64 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, qg = wave & 3;
+    const int hi = lane >> 5;
+    const int gx = (p.Lq + 127) / 128;
+    const int items = gx * p.H * p.B;
+    const int per = (items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    const int hb = item / gx, qblk = item - hb * gx;
+    const int b = hb / p.H, h = hb - b * p.H;
+    const int q0 = qblk * 128;
+    v8 qf[4];
+    {
+        const T* qrow = (const T*)p.Q + ((size_t)b * p.Lq + min(q0 + qg * 32 + (lane & 31), p.Lq - 1)) * p.ldq + h * 64 + hi * 8;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qrow + sd * 16);
+    }
+    f32x16 o[2], fin[2];
+    float m_run, l_run;
+    attn_core_ks<T>(p, smem + g * (2 * 2 * ATT_TILE_BYTES), qf, b, h, g, qg, lane, o, m_run, l_run);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // nobody reads the rings any more: merge buffer at 0, O staging rows behind it
+    attn_ks_merge((float*)smem, p.scale * LOG2E, g, qg, lane, o, m_run, l_run, fin);
+    if (g == 0) attn_store<T, 4>(p, smem + 4 * 34 * 64 * 4, fin, b, h, q0, qg, lane);
+    else tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid - 256, 256);
 }
 
 // ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
@@ -293,6 +331,19 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     constexpr int nw = 4;
     const int items = ((p.Lq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
     dim3 grid(8 * ((items + 7) / 8));
+    // one key set, an even number of whole key tiles, at least two per group: the key-split kernel (every SDXL self-attention)
+    if (!p.K2 && p.Lk % (2 * ATT_KV) == 0 && p.Lk >= 4 * ATT_KV && (g_attn_mode == 0 || g_attn_mode == 5 || g_attn_mode == 6)) {
+        const int lds = 2 * 2 * 2 * ATT_TILE_BYTES;
+        const int items128 = ((p.Lq + 127) / 128) * p.H * p.B;
+        dim3 grid2(8 * ((items128 + 7) / 8));
+        AttnParams q = p;
+        q.defer_log2 = g_attn_mode == 6 ? 0.0f : ATT_DEFER_LOG2;
+        if (dtype == IMH_DT_BF16) { static DynLdsOnce once; once.ensure((const void*)attn_ks_kernel<bf16_t>, lds);
+                                    hipLaunchKernelGGL((attn_ks_kernel<bf16_t>), grid2, dim3(512), lds, stream, q); }
+        else { static DynLdsOnce once; once.ensure((const void*)attn_ks_kernel<f16_t>, lds);
+               hipLaunchKernelGGL((attn_ks_kernel<f16_t>), grid2, dim3(512), lds, stream, q); }
+        return check_launch("attn_ks_kernel");
+    }
     if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || g_attn_mode == 3 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
         const int lds = ATT_PIPE_STAGES * 2 * ATT_TILE_BYTES;
         AttnParams q = p;

@@ -570,6 +570,136 @@ __device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned cha
         for (int r = 0; r < 16; ++r) fin[dt][r] = o[dt][r] * inv;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Key-split key loop (self-attention, one key set): the workgroup is TWO groups of four waves; group g runs the online softmax
+// over ITS half of the key tiles (own two-slot K / V^T ring, four waves x 32 queries share every tile as above) and the two
+// partial results (m, l, O) of a query row are merged once at the end (attn_ks_merge).  Why: at UNet batch 2 the L = 1024 layers
+// are 320 workgroups of 128 queries on 256 CUs -- most SIMDs held ONE wave, and a single wave cannot overlap its softmax VALU
+// with its MFMAs (profiles/r03_valu_mfma_rate_microbench.csv: MFMA + 6 VALU 54 cycles with one wave per SIMD, 33 with four).
+// Splitting the keys doubles the waves without shrinking the 128 queries that share a K / V^T tile; the body is the plain
+// in-order tile (QK^T -> softmax -> PV) held to 128 registers, so two workgroups = FOUR waves per SIMD fit a CU and the
+// overlap comes from the hardware's wave interleave instead of a hand-pipelined stream (attn_core_pipe: 222 registers, two
+// waves per SIMD).  One s_barrier per tile (both groups: the ring slots are group-private, the barrier is the workgroup's).
+// Deferred running maximum as in attn_core_pipe; every term is scaled exactly once (the decision precedes the tile's P).
+template <typename T>
+__device__ __forceinline__ void attn_core_ks(const AttnParams& p, unsigned char* gs, const typename Vec<T>::v8 (&qf)[4],
+                                             const int b, const int h, const int g, const int qg, const int lane,
+                                             f32x16 (&o)[2], float& m_run, float& l_run) {
+    typedef typename Vec<T>::v8 v8;
+    const int hi = lane >> 5;
+    (void)hi;
+    const float c = p.scale * LOG2E;
+    const float defer = p.defer_log2;
+    const T* Kp = (const T*)p.K;
+    const T* Vp = (const T*)p.Vt;
+    const int tg = (p.Lk / ATT_KV) >> 1;           // tiles per group (the launcher guarantees an even tile count, no ragged tile)
+    const int t0 = g * tg;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    m_run = NEG_BIG; l_run = 0.f;
+    auto stage = [&](int slot, int tile) {
+        unsigned char* ks = gs + slot * 2 * ATT_TILE_BYTES;
+        attn_stage_tile<T>(Kp, Vp, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, ks, ks + ATT_TILE_BYTES, qg, lane);
+    };
+    stage(0, t0);
+    for (int t = 0; t < tg; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile t (and, at t = 0, its Q fragments)
+        __builtin_amdgcn_s_barrier();                          // ... everyone's; every wave is past its reads of tile t - 1
+        asm volatile("" ::: "memory");
+        if (t + 1 < tg) stage((t + 1) & 1, t0 + t + 1);        // a whole tile of compute (x 4 waves per SIMD) to land in
+        const unsigned char* ks = gs + (t & 1) * 2 * ATT_TILE_BYTES;
+        const unsigned char* vs = ks + ATT_TILE_BYTES;
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            v8 kf[4];
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) kf[sd] = *(const v8*)(ks + att_k_off(lane, kt, sd));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) st[kt] = mfma32(kf[sd], qf[sd], st[kt]);
+        }
+        float mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
+        mx = fmaxf(mx, st[0][2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
+        mx = fmaxf(mx, st[1][15]);
+        mx = xhalf_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        if (__any((m_new - m_run) * c > defer)) {              // wave-uniform; m_run = NEG_BIG at t = 0 always takes it (alpha = 0)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const f32x2 c2 = {c, c};
+        const f32x2 nmc2 = {-m_run * c, -m_run * c};
+        f32x2 ps2 = {0.f, 0.f};
+        v8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 s2 = {st[kt][r], st[kt][r + 1]};
+                const f32x2 e2 = __builtin_elementwise_fma(s2, c2, nmc2);
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                ps2 += p2;
+                pf[kt][r >> 3][r & 7] = from_f32<T>(p2[0]);
+                pf[kt][r >> 3][(r & 7) + 1] = from_f32<T>(p2[1]);
+            }
+        l_run += ps2[0] + ps2[1];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8 vf[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vf[dt] = *(const v8*)(vs + att_v_off(lane, dt, kt, s2));
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[dt], pf[kt][s2], o[dt]);
+            }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Merge of the two key halves: group 1 parks (m, l, O) of its 128 query rows in LDS (lane-linear: register-major, lane-minor,
+// conflict-free), group 0 combines them with its own in a fixed order -- m = max(m0, m1), l = l0 a0 + l1 a1, O = O0 a0 + O1 a1
+// with a_i = 2^((m_i - m) c) -- and leaves fin = O / l.  `mb` = 4 x 8.5 KB (dead ring space; the caller's barrier before this
+// call guarantees nobody reads the rings any more).  Every wave of the workgroup must call it (one barrier inside).
+__device__ __forceinline__ void attn_ks_merge(float* mb, const float c, const int g, const int qg, const int lane, f32x16 (&o)[2],
+                                              const float m_run, const float l_run, f32x16 (&fin)[2]) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float* w = mb + qg * (34 * 64);
+    if (g == 1) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[(dt * 16 + r) * 64 + lane] = o[dt][r];
+        w[32 * 64 + lane] = m_run;
+        w[33 * 64 + lane] = l_tot;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g == 0) {
+        const float m1 = w[32 * 64 + lane], l1 = w[33 * 64 + lane];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * c), a1 = __builtin_amdgcn_exp2f((m1 - m) * c);
+        const float inv = 1.0f / (l_tot * a0 + l1 * a1);
+        const float f0 = a0 * inv, f1 = a1 * inv;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[dt][r] = o[dt][r] * f0 + w[(dt * 16 + r) * 64 + lane] * f1;
+    }
+}
+
 // O tile through the wave's private staging rows of smem (rows wave*32 ..): lane (q, hi) owns d = dt*32 + 8*rg + 4*hi + e,
 // written as 8-B pieces, read back as full 128-B rows (8 lanes x 16 B) and stored coalesced.  The caller guarantees that
 // no wave still reads the ring (attn_core ends with a workgroup barrier).

@@ -222,13 +222,14 @@ def sdpa_ref(q, k, v, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 5, 6])
 @pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192), (1, 3, 128), (2, 1, 320), (1, 2, 384), (1, 1, 448),
-                                    (1, 1, 512), (1, 2, 4096)])
+                                    (1, 1, 512), (1, 2, 4096), (2, 3, 640), (1, 2, 768)])
 def test_attention_self(L, dtype, mode, B, H, Lq):
-    """mode (imh_debug_set key 4): 1 = in-order key loop, 2 / 3 = software-pipelined key loop with the textbook / the deferred
-    running maximum (every tail of its unrolled tile
-    loop: 1 .. 8, 16, 64 tiles; a key count that is not a multiple of 64 always takes the in-order kernel)"""
+    """mode (imh_debug_set key 4): 0 = what the forward runs, 1 = in-order key loop, 2 / 3 = software-pipelined key loop with the
+    textbook / the deferred running maximum (every tail of its unrolled tile loop: 1 .. 8, 16, 64 tiles; a key count that is not a
+    multiple of 64 always takes the in-order kernel), 5 / 6 = key-split workgroups (two key halves x four query groups, merged
+    in LDS) with the deferred / the textbook maximum: an even number (>= 4) of whole key tiles, else the next kernel in line"""
     assert L.load().imh_debug_set(4, mode) == 0
     try:
         _attention_self_case(L, dtype, B, H, Lq)
@@ -246,6 +247,11 @@ def _attention_self_case(L, dtype, B, H, Lq):
     ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125)
     ref = sdpa_ref(qk[:, :C_].reshape(B, Lq, C_), qk[:, C_:].reshape(B, Lq, C_), v, H)
     assert_close(out.view(B, Lq, C_), ref, dtype, "self attention", k=6.0)
+    first = out.clone()
+    for _ in range(3):                                      # race screen of the rings / the key-split merge: bitwise repeatable
+        out.zero_()
+        ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125)
+        assert torch.equal(out, first), "self attention not bitwise repeatable"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -388,7 +394,7 @@ def test_fused_cross_attention_large_mean_rows(L, dtype, mode, how):
     assert zr < 0.2, f"zero-variance row rel-rms {zr:.3e}"
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 5])
 def test_attention_spiked_scores(L, mode):
     """forces the online-softmax rescale path: one key dominates late in the sequence (every key loop)"""
     assert L.load().imh_debug_set(4, mode) == 0
@@ -399,7 +405,7 @@ def test_attention_spiked_scores(L, mode):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 5, 6])
 def test_attention_creeping_maximum(L, dtype, mode):
     """the deferred running maximum (mode 3 = the default of the pipelined loop): every 64-key tile raises the row maxima by
     ~3 in the exponent domain, below the 2^8 deferral threshold per tile but 45 in total -- the rescale must fire every third
