@@ -35,7 +35,8 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.X = a->X; p.W = a->W; p.Y = a->Y; p.partial = a->partial; p.bias = a->bias; p.rowadd = a->rowadd;
     p.residual = a->residual; p.ln_s = a->ln_s; p.ln_c = a->ln_c; p.ln_eps = a->ln_eps;
     p.ln_stats = a->ln_stats; p.ln_stats_out = a->ln_stats_out; p.ln_slots = a->ln_slots; p.ln_slots_out = a->ln_slots_out;
-    p.gn_out = a->gn_out; p.gn_nblk = a->gn_nblk; p.gn_groups = a->gn_groups; p.gn_hw = a->gn_hw;
+    p.gn_out = a->gn_out; p.gn_nblk = a->gn_nblk; p.gn_hw = a->gn_hw;
+    p.gn_tab = a->gn_tab; p.gn_silu = a->gn_silu; p.X2 = a->X2; p.Cin1 = a->X2 ? a->Cin1 : a->Cin;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
@@ -138,7 +139,9 @@ static NormParams to_norm(const imh_norm_args* a) {
     NormParams p;
     p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.partial = a->partial;
     p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.rows = a->rows; p.eps = a->eps; p.silu = a->silu;
-    p.stats_blocks = a->stats_blocks;
+    p.mode = a->mode; p.table = a->table; p.partial2 = a->partial2;
+    p.nblk = a->nblk; p.sub = a->sub; p.npart = a->npart; p.C1 = a->C1; p.nblk2 = a->nblk2; p.sub2 = a->sub2; p.npart2 = a->npart2;
+    p.dtype_f16 = 0;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return p;
 }
@@ -181,10 +184,7 @@ static int run_op(const imh_op& o, hipStream_t s) {
     switch (o.kind) {
         case IMH_OP_GEMM: return do_gemm(&o.u.gemm, s);
         case IMH_OP_ATTN: return do_attn(&o.u.attn, s);
-        case IMH_OP_GROUPNORM: {
-            if (!o.u.norm.x || !o.u.norm.y) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }
-            return groupnorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
-        }
+        case IMH_OP_GROUPNORM: return groupnorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
         case IMH_OP_LAYERNORM: {
             if (!o.u.norm.x || !o.u.norm.y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
             return layernorm_launch(to_norm(&o.u.norm), o.u.norm.dtype, s);
@@ -248,10 +248,12 @@ int imh_cross_attention(const imh_xattn_args* a, void* stream) { return do_xattn
 int imh_attention_small(const imh_small_attn_args* a, void* stream) { return do_attn_small(a, (hipStream_t)stream); }
 
 int imh_groupnorm(const imh_norm_args* a, void* stream) {
-    if (!a || !a->x || !a->y) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }
+    if (!a) { set_error("groupnorm: null pointer argument"); return IMH_ERR_ARG; }
     return groupnorm_launch(to_norm(a), a->dtype, (hipStream_t)stream);
 }
 size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups) { return groupnorm_workspace_bytes(B, HW, C, groups); }
+int imh_groupnorm_stats_blocks(int HW, int C) { return groupnorm_stats_blocks(HW, C); }
+int imh_groupnorm_stats_sub(int C, int groups) { return groups > 0 && C % groups == 0 ? groupnorm_stats_sub(C, groups) : 0; }
 int imh_layernorm(const imh_norm_args* a, void* stream) {
     if (!a || !a->x || !a->y) { set_error("layernorm: null pointer argument"); return IMH_ERR_ARG; }
     return layernorm_launch(to_norm(a), a->dtype, (hipStream_t)stream);

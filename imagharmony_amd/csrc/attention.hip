@@ -332,7 +332,9 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     const int items = ((p.Lq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
     dim3 grid(8 * ((items + 7) / 8));
     // one key set, an even number of whole key tiles, at least two per group: the key-split kernel (every SDXL self-attention)
-    if (!p.K2 && p.Lk % (2 * ATT_KV) == 0 && p.Lk >= 4 * ATT_KV && (g_attn_mode == 0 || g_attn_mode == 5 || g_attn_mode == 6)) {
+    // (auto keeps the software-pipelined kernel: the two measure the same in the forward, 38.4 vs 38.7 us per launch,
+    // profiles/r04_forward_ab_attn.json)
+    if (!p.K2 && p.Lk % (2 * ATT_KV) == 0 && p.Lk >= 4 * ATT_KV && (g_attn_mode == 5 || g_attn_mode == 6)) {
         const int lds = 2 * 2 * 2 * ATT_TILE_BYTES;
         const int items128 = ((p.Lq + 127) / 128) * p.H * p.B;
         dim3 grid2(8 * ((items128 + 7) / 8));

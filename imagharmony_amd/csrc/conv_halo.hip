@@ -16,6 +16,14 @@
 //   * LDS: 2 x 23 KB halo + 2 x 40 KB weights = 126 KB (86 KB for the 160-cout form), one workgroup per CU; two-stage pipeline over the
 //     9 * Cin / 64 (chunk, tap) steps, the next chunk's halo issued at tap 0 (nine steps of slack).
 // Epilogue: the shared one (bias, time-embedding row-add, residual).  Roofline: MFMA-bound, 2 * M * Cout * 9 Cin FLOP.
+//
+// Round 4: the ResnetBlock2D front end (diffusers: norm -> SiLU -> conv, SURVEY.md 2.2 "GroupNorm(32)+SiLU") lives in the halo
+// staging.  With p.gn_tab the halo of a 64-channel chunk is DMA-staged RAW and then normalised IN PLACE in LDS by the wave that
+// staged it -- y = silu(x * scale[b, c] + shift[b, c]), the per-sample (scale, shift) table of norm.hip gn_table_kernel copied to LDS
+// once per workgroup -- before the nine taps read it: one transform per staged pixel (amortised over 9 taps x all couts), padding
+// pixels stay zero (the conv pads the NORMALISED tensor), and the normalised activation never exists in memory (the gn_apply pass:
+// a read + write of the whole tensor per GroupNorm).  With p.X2 the input is a channel concat [X | X2] (the up path's skip
+// connections) read from its two producers chunk by chunk: the concat pass disappears as well.
 #include "imh_common.h"
 #include "imh_kernels.h"
 #include "imh_gemm_epilogue.h"
@@ -69,6 +77,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo0 = smem;
     unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
+    const float* const gtab = (const float*)(smem + 2 * CH_HALO_BYTES + S * CH_W_BYTES);     // [Cin][2] (scale, shift) of this sample (p.gn_tab)
     static_assert(S >= 2 && (S - 2) * WQ + HQ <= 15, "vmcnt switch range");
 
     const int tid = threadIdx.x;
@@ -86,7 +95,10 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     const int Hv = p.H << p.up, Wv = p.Wd << p.up;          // virtual (upsampled) input = output size (stride 1)
 
     // ---- halo staging: 23 pieces of 8 halo pixels; this wave takes pieces wave, wave + 8, wave + 16 ----
+    // (two sources: channels [0, Cin1) from X, the rest from X2 -- a channel concat read from its producers; Cin1 = Cin without X2)
+    const int cpt1 = p.Cin1 / GEMM_BK;
     const unsigned char* hsrc[HQ];
+    const unsigned char* hsrc2[HQ];
     int hstep[HQ];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
@@ -97,14 +109,42 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
         const bool ok = piece < HPIECES && h < CH_HALO && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
         const int c = (lane & 7) ^ (h & 7);
         const size_t pix = ((size_t)b * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up);
-        hsrc[q] = ok ? (const unsigned char*)p.X + pix * p.Cin * sizeof(T) + c * 16 : g_zero_page + c * 16;
+        hsrc[q] = ok ? (const unsigned char*)p.X + pix * p.Cin1 * sizeof(T) + c * 16 : g_zero_page + c * 16;
+        hsrc2[q] = (ok && p.X2) ? (const unsigned char*)p.X2 + pix * (p.Cin - p.Cin1) * sizeof(T) + c * 16 : g_zero_page + c * 16;
         hstep[q] = ok ? GEMM_BK * (int)sizeof(T) : 0;
     }
     auto stage_halo = [&](int buf, int ct) {
         unsigned char* d = halo0 + buf * CH_HALO_BYTES;
+        const bool second = ct >= cpt1;                     // wave-uniform
+        const int cc = second ? ct - cpt1 : ct;
 #pragma unroll
         for (int q = 0; q < HQ; ++q)
-            if (q * 8 + wave < HPIECES) glds16(hsrc[q] + (size_t)ct * hstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+            if (q * 8 + wave < HPIECES) glds16((second ? hsrc2[q] : hsrc[q]) + (size_t)cc * hstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+    };
+    // GroupNorm (+ SiLU) of the staged chunk, in place, by the wave that staged it (its own DMA pieces: its own vmcnt wait covers them);
+    // every piece of a lane holds the same logical 16-B chunk (h & 7 == (lane >> 3) & 7 whatever the piece), i.e. the same 8 channels
+    const int gch = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+    auto norm_halo = [&](int buf, int ct) {
+        unsigned char* d = halo0 + buf * CH_HALO_BYTES;
+        float sc[8], sh[8];
+        const f32x4* tb = (const f32x4*)(gtab + (ct * GEMM_BK + gch) * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            if (q * 8 + wave < HPIECES) {
+                v8* a = (v8*)(d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES + lane * 16);
+                const v8 t = *a;
+                v8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = __builtin_fmaf(to_f32(t[e]), sc[e], sh[e]);
+                    if (p.gn_silu) f = silu_f(f);
+                    o[e] = from_f32<T>(f);
+                }
+                if (hstep[q] != 0) *a = o;                  // padding pixels stay zero: the conv pads the normalised tensor
+            }
+        }
     };
     // ---- weight staging: 40 pieces of 8 rows; this wave takes pieces wave + 8 q ----
     const unsigned char* wsrc[WQ];
@@ -147,10 +187,22 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     const int nW = (WQ - 1) + ((WQ - 1) * 8 + wave < WPIECES ? 1 : 0);
     const int nH = (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
     auto step_ct = [&](int st) { return st / 9; };
+    const bool gn = p.gn_tab != nullptr;
+    if (gn) {                                           // this sample's (scale, shift) table -> LDS, before any LDS-DMA is in flight
+        const f32x4* src = (const f32x4*)(p.gn_tab + (size_t)b * p.Cin * 2);
+        f32x4* dst = (f32x4*)gtab;
+        for (int i = tid; i < p.Cin / 2; i += 512) dst[i] = src[i];
+        __syncthreads();
+    }
     stage_halo(0, 0);                                   // oldest: whoever waits for weight step 0 has the first halo too
 #pragma unroll
     for (int j = 0; j < S - 1; ++j)
         if (j < nsteps) stage_w(j % S, step_ct(j), j - 9 * step_ct(j));
+    if (gn) {                                           // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
+        wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
+        norm_halo(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written back before the barrier of step 0 publishes the halo
+    }
     int step = 0;
     for (int ct = 0; ct < cpt; ++ct) {
         const unsigned char* hb = halo0 + (ct & 1) * CH_HALO_BYTES;
@@ -168,6 +220,9 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
                 stage_w(ns % S, nct, ns - 9 * nct);                  // into the slot of step - 1
             }
             if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
+            // ... and normalised in place once it has landed for this wave: the wait above stops counting it from tap S on (it is older
+            // than every weight step still in flight); the barrier of the next chunk's tap 0 publishes the result
+            if (gn && tap == S && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1);
             const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES;
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
 #pragma unroll
@@ -198,10 +253,8 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     const int ox = tx * CH_PW + (lane & 15);
     // GroupNorm partials of the output for the GroupNorm that reads it (norm2 after conv1, the next block's norm after conv2):
     // a wave's FM patch rows x 16 pixels are one partial block
-    constexpr int GNS = (4 * FN) / 10;
-    float gn_flat[2 * GNS];
-#pragma unroll
-    for (int k = 0; k < 2 * GNS; ++k) gn_flat[k] = 0.f;
+    GnAcc<4 * FN> gna;
+    gn_zero(gna);
     auto row = [&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (i < FM) {
@@ -214,19 +267,14 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
             const float none[8 * FN] = {};
-            epilogue_store_pre<T, FN>(p, v, m, nb, none, false, nullptr, nullptr, lane, gn_flat);
+            epilogue_store_pre<T, FN>(p, v, m, nb, none, false, nullptr, nullptr, lane, &gna, i == 0);
         }
     };
     row(std::integral_constant<int, 0>{});
     row(std::integral_constant<int, 1>{});
     row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{});
-    if (p.gn_out) {
-        float gs[GNS], gq[GNS];
-#pragma unroll
-        for (int k = 0; k < GNS; ++k) { gs[k] = gn_flat[k]; gq[k] = gn_flat[GNS + k]; }
-        gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, b, (ty * tiles_x + tx) * 4 + wm, nb, gs, gq, lane);
-    }
+    if (p.gn_out) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.N / 10, b, (ty * tiles_x + tx) * 4 + wm, nb, gna, FM, lane);
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
@@ -247,7 +295,13 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     const int B = p.M / (p.Ho * p.Wo);
     const int tiles_x = (p.Wo + CH_PW - 1) / CH_PW, tiles_y = (p.Ho + ph - 1) / ph, tiles_n = (p.N + bn - 1) / bn;
     dim3 grid(B * tiles_y * tiles_x * tiles_n);
-    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * bn * GEMM_ROW_BYTES;
+    if (p.gn_tab && p.up) { set_error("conv_halo: the fused GroupNorm front end and the fused upsampling are separate forms"); return IMH_ERR_ARG; }
+    if (p.Cin1 % GEMM_BK != 0 || p.Cin1 <= 0 || p.Cin1 > p.Cin || (p.X2 == nullptr) != (p.Cin1 == p.Cin)) {
+        set_error("conv_halo: Cin1=%d must be a positive multiple of 64, = Cin=%d exactly when there is no second source", p.Cin1, p.Cin);
+        return IMH_ERR_ARG;
+    }
+    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * bn * GEMM_ROW_BYTES + (p.gn_tab ? p.Cin * 8 : 0);
+    if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
 #define IMH_CH3(TT, FNV, FMV, SV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)

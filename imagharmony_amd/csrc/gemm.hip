@@ -70,7 +70,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
     const unsigned char* zero = g_zero_page;
 
     const unsigned char* xbase[RX];
+    const unsigned char* xbase2[RX];       // second token source (p.X2: K columns [Cin1, K) of a column concat), dense rows of K - Cin1
     int xstep[RX];
+    const int kt_x2 = (!CONV && p.X2) ? p.Cin1 / GEMM_BK : 0x7fffffff;
     // conv decomposition of the output pixel handled by this staging row
     int cb[RX], coy[RX], cox[RX];
     bool cvalid[RX];
@@ -79,9 +81,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
         const int row = stage_row(i, wave, lane);
         const int c = stage_chunk_x(row, lane);
         const int m = m0 + row;
+        xbase2[i] = zero + c * 16;
         if (!CONV) {
             const bool ok = m < p.M;
             xbase[i] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+            if (ok && p.X2) xbase2[i] = (const unsigned char*)p.X2 + ((size_t)m * (p.K - p.Cin1)) * sizeof(T) + c * 16;
             xstep[i] = ok ? GEMM_BK * (int)sizeof(T) : 0;
         } else {
             const bool ok = m < p.M;
@@ -128,9 +132,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, co
                 glds16(src, xs + stage_lds_off(i, wave));
             }
         } else {
+            const bool second = kt >= kt_x2;            // wave-uniform
 #pragma unroll
             for (int i = 0; i < RX; ++i)
-                glds16(xbase[i] + (size_t)kt * xstep[i], xs + stage_lds_off(i, wave));
+                glds16(second ? xbase2[i] + (size_t)(kt - kt_x2) * xstep[i] : xbase[i] + (size_t)kt * xstep[i], xs + stage_lds_off(i, wave));
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i)
@@ -472,16 +477,30 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     }
     if (p.gn_out) {
         const int rows = gemm_gn_block_rows(bm, bn);
-        const int cpg = p.gn_groups > 0 ? p.N / p.gn_groups : 0;
         const bool halo = bm >= 7000 && bm < 8000;
-        if (rows == 0 || p.gn_groups <= 0 || p.N % p.gn_groups || (cpg != 10 && cpg != 20 && cpg != 40) || p.N % (halo ? bn : 80) ||
-            p.gn_hw <= 0 || p.gn_hw % rows || p.M % p.gn_hw || p.gn_nblk != p.gn_hw / rows || p.splits > 1 ||
-            (p.flags & (GF_GEGLU | GF_VT_PERM | GF_OUT_F32 | GF_LN_ROW | GF_LN_COL)) ||
+        if (rows == 0 || p.N % 10 || p.N % (halo ? bn : 80) || p.gn_hw <= 0 || p.gn_hw % rows || p.M % p.gn_hw || p.gn_nblk != p.gn_hw / rows ||
+            p.splits > 1 || (p.flags & (GF_GEGLU | GF_VT_PERM | GF_OUT_F32 | GF_LN_ROW | GF_LN_COL)) ||
             (halo && (p.Ho % (rows * 4 / 16) || p.Wo % 16))) {
-            set_error("gemm: gn_out needs a variant with a GroupNorm epilogue (%d rows per block for %dx%d), 10 / 20 / 40 channels per group, "
-                      "whole tiles, gn_nblk == gn_hw / rows (N=%d groups=%d hw=%d nblk=%d M=%d flags=%d)", rows, bm, bn, p.N, p.gn_groups, p.gn_hw, p.gn_nblk, p.M, p.flags);
+            set_error("gemm: gn_out needs a variant with a GroupNorm epilogue (%d rows per block for %dx%d), N a multiple of 10 and of the tile "
+                      "width, whole tiles, gn_nblk == gn_hw / rows (N=%d hw=%d nblk=%d M=%d flags=%d)", rows, bm, bn, p.N, p.gn_hw, p.gn_nblk, p.M, p.flags);
             return IMH_ERR_ARG;
         }
+    }
+    {
+        const bool halo = bm >= 7000 && bm < 8000;
+        const bool ws = bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128;
+        if (p.gn_tab && !(conv && halo)) {
+            set_error("gemm: the fused GroupNorm front end (gn_tab) is a form of the LDS-halo conv3x3 (variant %d)", bm);
+            return IMH_ERR_ARG;
+        }
+        if (p.X2 && conv && !halo) { set_error("gemm: a two-source conv input (X2) needs the LDS-halo conv3x3 (variant %d)", bm); return IMH_ERR_ARG; }
+        if (p.X2 && !conv) {      // token operand = column concat [X | X2]: plain tiles and the wave-specialised variants
+            if (!(bm <= 128 || ws) || p.Cin1 <= 0 || p.Cin1 >= p.K || p.Cin1 % GEMM_BK || (p.flags & (GF_LN_ROW | GF_LN_COL | GF_VT_PERM))) {
+                set_error("gemm: X2 needs a plain or wave-specialised variant, 0 < Cin1 < K, Cin1 %% 64 == 0, no folded LayerNorm (bm=%d Cin1=%d K=%d)", bm, p.Cin1, p.K);
+                return IMH_ERR_ARG;
+            }
+        }
+        if (!p.X2) p.Cin1 = conv ? p.Cin : p.K;
     }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);
     if (dtype == IMH_DT_F16) return launch_typed<f16_t>(p, conv, bm, bn, stream);

@@ -445,6 +445,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         const int pw = wave - NC;
         const unsigned char* zero = g_zero_page;
         const unsigned char* base[LP];
+        const unsigned char* base2[KX > 0 ? KX : 1];      // second token source (p.X2: K columns [Cin1, K), dense rows)
+        const int kt_x2 = (!CONV && p.X2) ? p.Cin1 / GEMM_BK : 0x7fffffff;
         int step[LP];
         int cb[KX > 0 ? KX : 1], coy[KX > 0 ? KX : 1], cox[KX > 0 ? KX : 1];
         bool cvalid[KX > 0 ? KX : 1];
@@ -455,8 +457,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                 const int c = stage_chunk_x(r, lane);
                 const int m = m0 + r;
                 const bool ok = m < p.M;
+                base2[k] = zero + c * 16;
                 if (!CONV) {
                     base[k] = ok ? (const unsigned char*)p.X + ((size_t)m * p.ldx) * sizeof(T) + c * 16 : zero + c * 16;
+                    if (ok && p.X2) base2[k] = (const unsigned char*)p.X2 + ((size_t)m * (p.K - p.Cin1)) * sizeof(T) + c * 16;
                     step[k] = ok ? GEMM_BK * (int)sizeof(T) : 0;
                 } else {
                     const int hw = p.Ho * p.Wo;
@@ -500,6 +504,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                         ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
                         : zero + c * 16;
                     if (!(WS_ABL & 2)) glds16(src, dst);
+                } else if (!CONV && k < KX && kt >= kt_x2) {
+                    if (!(WS_ABL & 2)) glds16(base2[k] + (size_t)(kt - kt_x2) * step[k], dst);
                 } else {
                     if (!(WS_ABL & 2)) glds16(base[k] + (size_t)kt * step[k], dst);
                 }
@@ -625,10 +631,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     LnArgs<4 * FN> ln;
     float st_s[FM], st_q[FM];
     // GroupNorm partials of the output (for the GroupNorm that reads it; imh_lnstats.h gn_emit): sub-runs of 10 channels
-    constexpr int GNS = (4 * FN) % 10 == 0 ? (4 * FN) / 10 : 1;
-    float gn_s[GNS], gn_q[GNS], gn_flat[2 * GNS];
-#pragma unroll
-    for (int k = 0; k < GNS; ++k) { gn_s[k] = 0.f; gn_q[k] = 0.f; gn_flat[k] = 0.f; gn_flat[GNS + k] = 0.f; }
+    constexpr int GNV = (4 * FN) % 10 == 0 ? 4 * FN : 10;
+    GnAcc<GNV> gna;
+    gn_zero(gna);
     if constexpr (LN == 2) {
         const f32x2s* ex = (const f32x2s*)(smem + S * STAGE);
 #pragma unroll
@@ -713,13 +718,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                 stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
                 if (p.ln_stats_out) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
                 if constexpr (NV % 10 == 0) {
-                    if (p.gn_out) gn_accumulate<T, NV>(v, gn_s, gn_q);
+                    if (p.gn_out) gn_accumulate<T, NV>(v, gna, i == 0);
                 }
             }
             if constexpr (NV % 10 == 0) {
                 if (p.gn_out) {
                     const int mw = m0 + wm * TM;
-                    if (mw < p.M) gn_emit<NV>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gn_s, gn_q, lane);
+                    if (mw < p.M) gn_emit<NV>(p.gn_out, p.gn_nblk, p.N / 10, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gna, FM, lane);      // (wave-uniform guard: the butterflies inside need the whole wave)
                 }
             }
             return;
@@ -746,15 +751,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         } else {
             if constexpr (LN == 1) { ln.mean = st_s[i]; ln.rstd = st_q[i]; }
             epilogue_store_pre<T, FN>(p, v, m, nb, lnpre, have_pre, LN != 0 ? &ln : nullptr, LN != 0 ? nullptr : &pre, lane,
-                                      (LN == 0 && (4 * FN) % 10 == 0) ? gn_flat : nullptr);
+                                      (LN == 0 && (4 * FN) % 10 == 0) ? &gna : nullptr, i == 0);
         }
     }
     if constexpr (LN == 0 && (4 * FN) % 10 == 0) {
         if (p.gn_out && p.splits == 1) {
-#pragma unroll
-            for (int k = 0; k < GNS; ++k) { gn_s[k] = gn_flat[k]; gn_q[k] = gn_flat[GNS + k]; }
             const int mw = m0 + wm * TM;
-            if (mw < p.M) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.gn_groups, p.N / p.gn_groups, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gn_s, gn_q, lane);
+            if (mw < p.M) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.N / 10, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gna, FM, lane);
         }
     }
 }

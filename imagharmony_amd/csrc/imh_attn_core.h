@@ -599,9 +599,25 @@ __device__ __forceinline__ void attn_core_ks(const AttnParams& p, unsigned char*
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     m_run = NEG_BIG; l_run = 0.f;
+    // staging sources of this lane for key tile 0 (rows qg*8 + lane/8 and + 32 of the K tile / the V^T tile); a tile step is a
+    // wave-uniform byte offset, so the loop carries no per-lane 64-bit address arithmetic
+    const unsigned char* ksrc[2];
+    const unsigned char* vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + qg * 8 + (lane >> 3);
+        const int ch = stage_chunk_x(row, lane);
+        ksrc[i] = (const unsigned char*)(Kp + ((size_t)b * p.Lk_pad + row) * p.ldk + h * 64 + ch * 8);
+        vsrc[i] = (const unsigned char*)(Vp + ((size_t)h * 64 + row) * p.ldvt + (size_t)b * p.Lk_pad + ch * 8);
+    }
+    const size_t kstep = (size_t)ATT_KV * p.ldk * sizeof(T), vstep = (size_t)ATT_KV * sizeof(T);
     auto stage = [&](int slot, int tile) {
         unsigned char* ks = gs + slot * 2 * ATT_TILE_BYTES;
-        attn_stage_tile<T>(Kp, Vp, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, ks, ks + ATT_TILE_BYTES, qg, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(ksrc[i] + tile * kstep, ks + (i * 32 + qg * 8) * 128);
+            glds16(vsrc[i] + tile * vstep, ks + ATT_TILE_BYTES + (i * 32 + qg * 8) * 128);
+        }
     };
     stage(0, t0);
     for (int t = 0; t < tg; ++t) {

@@ -160,7 +160,8 @@ template <typename T, int FN>
 __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&v)[4 * FN], int m, int nb,
                                                    const float (&lnpre)[8 * FN], const bool have_pre,
                                                    const LnArgs<4 * FN>* ln = nullptr, const EpiPre<4 * FN>* pre = nullptr,
-                                                   const int lane = -1, float* gn_acc = nullptr) {
+                                                   const int lane = -1, GnAcc<(4 * FN) % 10 == 0 ? 4 * FN : 10>* gn_acc = nullptr,
+                                                   const bool gn_first = false) {
     constexpr int NV = 4 * FN;
     constexpr int NH = NV / 2;
     const T* bias = (const T*)p.bias;
@@ -270,15 +271,8 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
     // statistics hand-over to the LayerNorm-folding consumer of Y (the launcher only sets ln_stats_out for variants that pass
     // their lane here, for full-width slots: N % (4 * NV) == 0, and for plain T outputs)
     if (p.ln_stats_out && lane >= 0) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
-    if constexpr (NV % 10 == 0) {      // GroupNorm partials of the output (gn_acc = [2][NV / 10], the caller reduces and stores them)
-        if (gn_acc && p.gn_out) {      // gn_acc itself must be a compile-time null / array (a selected pointer would pin the array to scratch)
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const float r = to_f32(from_f32<T>(v[q]));
-                gn_acc[q / 10] += r;
-                gn_acc[NV / 10 + q / 10] = __builtin_fmaf(r, r, gn_acc[NV / 10 + q / 10]);
-            }
-        }
+    if constexpr (NV % 10 == 0) {      // GroupNorm partials of the output (the caller merges the lanes and stores them: gn_emit)
+        if (gn_acc && p.gn_out) gn_accumulate<T, NV>(v, *gn_acc, gn_first);     // gn_acc itself must be a compile-time null / object (a selected pointer would pin it to scratch)
     }
     if (fast) stv<T, NV>(y, v);
     else {

@@ -25,9 +25,15 @@ struct GemmParams {
     float* ln_stats_out;
     int ln_slots, ln_slots_out;
     // GroupNorm statistics of THIS launch's output (NHWC rows = pixels), for the GroupNorm that reads it: per (sample, pixel block of
-    // one wave's rows, group) the (sum, sum of squares) of the values as stored -- the layout of the GroupNorm kernel's own first pass
+    // one wave's rows, sub-run of 10 channels) the (sum, M2) of the values as stored (imh_lnstats.h gn_emit)
     float* gn_out;
-    int gn_nblk, gn_groups, gn_hw;
+    int gn_nblk, gn_hw;
+    // GroupNorm (+ SiLU) of the INPUT applied inside the conv's halo staging (conv_halo.hip): table[b][Cin][2] = (scale, shift)
+    const float* gn_tab;
+    int gn_silu;
+    // channel concat as the conv input: channels [0, Cin1) come from X (pixel stride Cin1), [Cin1, Cin) from X2 (pixel stride Cin - Cin1)
+    const void* X2;
+    int Cin1;
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;
@@ -43,8 +49,8 @@ struct GemmParams {
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
 size_t gemm_workspace_bytes(int M, int N, int splits);
-int gemm_stats_slot_width(int bm, int bn);
-int gemm_gn_block_rows(int bm, int bn);         // pixels per gn_out block of a tile variant (one wave's rows), 0 = no GroupNorm epilogue     // channels per ln_stats_out slot of a tile variant, 0 = no statistics epilogue
+int gemm_stats_slot_width(int bm, int bn);       // channels per ln_stats_out slot of a tile variant, 0 = no statistics epilogue
+int gemm_gn_block_rows(int bm, int bn);         // pixels per gn_out block of a tile variant (one wave's rows), 0 = no GroupNorm epilogue
 int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
 int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream);
 
@@ -106,12 +112,21 @@ struct NormParams {
     int rows;         // layer norm: rows
     float eps;
     int silu;
-    int stats_blocks; // group norm: > 0 = `partial` holds that many producer-written partial blocks per sample (no statistics pass)
+    // group norm (norm.hip): mode 0 statistics + table + apply, 1 statistics only, 2 table from partials, 3 apply a table
+    int mode;
+    float* table;             // [B][C][2] (scale, shift)
+    const float* partial2;    // second producer's partials (channel concat) or null
+    int nblk, sub, npart;     // source 1: partial blocks per sample, channels per sub-run, elements per partial (0 = ragged stats-kernel blocks)
+    int C1;                   // channels covered by source 1
+    int nblk2, sub2, npart2;
+    int dtype_f16;            // (set by the launcher)
     const void* pf_ptr;   // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
 };
 int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream);
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int groupnorm_stats_blocks(int HW, int C);
+int groupnorm_stats_sub(int C, int groups);
 int layernorm_launch(const NormParams& p, int dtype, hipStream_t stream);
 
 struct EwParams {

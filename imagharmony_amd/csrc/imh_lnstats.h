@@ -53,45 +53,56 @@ __device__ __forceinline__ void emit_row_stats(float* stats, const int slots, co
     }
 }
 
-// GroupNorm partials from a GEMM / conv epilogue.  A lane accumulates (sum, sum of squares) of its NV = 20 / 40 consecutive output
-// channels in sub-runs of 10 (the finest SDXL group: C = 320 / 32) over its rows; here the 16 lanes of a 16-lane group (= 16 rows)
-// are added up, sub-runs merged to the group width cpg (10, 20 or 40 channels; at cpg = 40 with NV = 20 two neighbouring lane
-// groups form one group), and one lane per group stores the pair.  partial[((b * nblk + blk) * groups + g) * 2 + {0, 1}].
+// GroupNorm partials from a GEMM / conv epilogue (format 2, round 4): ONE (sum, M2) pair per (sample, pixel block = one wave's
+// rows, sub-run of 10 consecutive output channels -- the finest SDXL group, C = 320 / 32), M2 = sum of squared deviations from
+// the PARTIAL's own mean, both taken from the values as stored (rounded to T).  Any consumer grouping (10 / 20 / 30 / 40 / 60 / 80
+// channels per group, also across the two producers of a channel concat) is assembled from sub-runs by the finalise kernel
+// (norm.hip gn_table_kernel).  No E[x^2] - mean^2 anywhere: a lane accumulates sum(x - p), sum((x - p)^2) about a PIVOT p (the
+// first value of its sub-run), converts to (sum, M2) and the 16 lanes of a lane group (= 16 rows) merge by equal-count Chan
+// butterflies -- a common offset of the tensor costs no precision (diffusers GroupNorm = torch.nn.GroupNorm, two-pass).
+// partial[((b * nblk + blk) * (N / 10) + nb / 10 + k) * 2 + {0, 1}], n = 160 * FM elements each.
 template <int NV>
-__device__ __forceinline__ void gn_emit(float* out, const int nblk, const int groups, const int cpg, const int b, const int blk,
-                                        const int nb, float (&gs)[NV / 10], float (&gq)[NV / 10], const int lane) {
-    constexpr int NS = NV / 10;
+struct GnAcc {
+    float s[NV / 10], q[NV / 10], pv[NV / 10];
+};
+template <int NV>
+__device__ __forceinline__ void gn_zero(GnAcc<NV>& g) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { gs[k] += __shfl_xor(gs[k], o, 64); gq[k] += __shfl_xor(gq[k], o, 64); }
-    float* base = out + ((size_t)b * nblk + blk) * groups * 2;
-    if (cpg == 10) {
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { f32x2s o2 = {gs[k], gq[k]}; *(f32x2s*)(base + (nb / 10 + k) * 2) = o2; }
-        }
-    } else if (cpg == 20) {
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int k = 0; k < NS; k += 2) { f32x2s o2 = {gs[k] + gs[k + 1], gq[k] + gq[k + 1]}; *(f32x2s*)(base + (nb / 20 + k / 2) * 2) = o2; }
-        }
-    } else {        // cpg == 40
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) { s += gs[k]; q += gq[k]; }
-        if constexpr (NV == 20) { s = xor16_sum(s); q = xor16_sum(q); }      // lane groups (0,1) and (2,3) hold the two halves
-        if ((lane & (NV == 20 ? 31 : 15)) == 0) { f32x2s o2 = {s, q}; *(f32x2s*)(base + (nb / 40) * 2) = o2; }
-    }
+    for (int k = 0; k < NV / 10; ++k) { g.s[k] = 0.f; g.q[k] = 0.f; g.pv[k] = 0.f; }
 }
-// per-row accumulation of the lane's values as stored (rounded to T)
+// one row of the lane's NV values as stored; first = the lane's first row (sets the pivots)
 template <typename T, int NV>
-__device__ __forceinline__ void gn_accumulate(const float* v, float (&gs)[NV / 10], float (&gq)[NV / 10]) {
+__device__ __forceinline__ void gn_accumulate(const float* v, GnAcc<NV>& g, const bool first) {
+    if (first) {
+#pragma unroll
+        for (int k = 0; k < NV / 10; ++k) g.pv[k] = to_f32(from_f32<T>(v[k * 10]));
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-        const float r = to_f32(from_f32<T>(v[q]));
-        gs[q / 10] += r;
-        gq[q / 10] = __builtin_fmaf(r, r, gq[q / 10]);
+        const float r = to_f32(from_f32<T>(v[q])) - g.pv[q / 10];
+        g.s[q / 10] += r;
+        g.q[q / 10] = __builtin_fmaf(r, r, g.q[q / 10]);
+    }
+}
+// rows = rows accumulated per lane (FM); every lane of the wave must call this (butterflies)
+template <int NV>
+__device__ __forceinline__ void gn_emit(float* out, const int nblk, const int nsub, const int b, const int blk, const int nb,
+                                        const GnAcc<NV>& g, const int rows, const int lane) {
+    float* base = out + (((size_t)b * nblk + blk) * nsub + nb / 10) * 2;
+#pragma unroll
+    for (int k = 0; k < NV / 10; ++k) {
+        float n = 10.0f * (float)rows;
+        float sum = __builtin_fmaf(n, g.pv[k], g.s[k]);
+        float m2 = fmaxf(g.q[k] - g.s[k] * g.s[k] / n, 0.f);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const float so = __shfl_xor(sum, o, 64), mo = __shfl_xor(m2, o, 64);
+            const float d = sum - so;
+            m2 = m2 + mo + d * d / (2.0f * n);
+            sum += so;
+            n *= 2.0f;
+        }
+        if ((lane & 15) == 0) { f32x2s o2 = {sum, m2}; *(f32x2s*)(base + k * 2) = o2; }
     }
 }
 

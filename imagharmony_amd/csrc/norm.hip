@@ -14,75 +14,168 @@ namespace imh {
 constexpr int GN_THREADS = 512;
 constexpr int GN_ELEMS_PER_BLOCK = 8192;     // 32768 left the 32 x 32 levels (1.3 M elements per sample) on 80 workgroups of 256 CUs
 
+// GroupNorm in three steps (diffusers ResnetBlock2D.norm1/norm2 + SiLU, Transformer2DModel.norm, conv_norm_out; torch.nn.GroupNorm
+// semantics: fp32 statistics, biased variance):
+//   1 statistics  (sum, M2) partials per (sample, pixel block, sub-run of `sub` consecutive channels), the format of
+//                 imh_lnstats.h gn_emit.  Either from the epilogue of the launch that WROTE the tensor (imh_gemm_args.gn_out, sub = 10) or
+//                 from gn_stats_kernel below (a pass over the tensor) -- Welford / Chan, never E[x^2] - mean^2.
+//   2 table       gn_table_kernel: per sample the partials of one or TWO producers (the second = the other half of a channel
+//                 concat) are merged per group in double precision, then scale[c] = gamma[c] * rstd[g(c)], shift[c] = beta[c] - mean *
+//                 scale[c] -> table[b][c][2] fp32.
+//   3 apply       y = silu?(x * scale + shift): gn_apply_kernel (a pass), or INSIDE the consuming conv3x3's halo staging
+//                 (conv_halo.hip, imh_gemm_args.gn_tab): the normalised tensor never exists in memory.
 static inline int gn_nblk(int HW, int C) {
     long long e = (long long)HW * C;
     int n = (int)((e + GN_ELEMS_PER_BLOCK - 1) / GN_ELEMS_PER_BLOCK);
     return n < 1 ? 1 : (n > 256 ? 256 : n);
 }
+// channels per sub-run of the stand-alone statistics kernel: 10 where the producers' epilogues use it (every SDXL UNet width), else
+// the group width itself (VAE: 4 / 8 / 16 channels per group)
+static inline int gn_sub(int C, int groups) {
+    const int cpg = C / groups;
+    return (cpg % 10 == 0) ? 10 : cpg;
+}
+int groupnorm_stats_blocks(int HW, int C) { return gn_nblk(HW, C); }
+int groupnorm_stats_sub(int C, int groups) { return gn_sub(C, groups); }
 
 size_t groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
-    return (size_t)B * gn_nblk(HW, C) * groups * 2 * sizeof(float);
+    const size_t part = (size_t)B * gn_nblk(HW, C) * (C / gn_sub(C, groups)) * 2 * sizeof(float);
+    return ((part + 255) & ~(size_t)255) + (size_t)B * C * 2 * sizeof(float);
 }
 
-// pass 1: per-(batch, block, group) partial sum / sum of squares.
-// thread t < CL*P: channel chunk cl = t % CL (8 channels), pixel lane pl = t / CL.
+// generic Chan merge of (n, sum, M2) += (nb, sb, mb)
+__device__ __forceinline__ void chan_merge(float& n, float& s, float& m2, const float nb, const float sb, const float mb) {
+    if (nb <= 0.f) return;
+    if (n <= 0.f) { n = nb; s = sb; m2 = mb; return; }
+    const float nn = n + nb;
+    const float d = sb / nb - s / n;
+    m2 = m2 + mb + d * d * (n * nb / nn);
+    s += sb;
+    n = nn;
+}
+
+// step 1, stand-alone: thread t < CL*P: channel chunk cl = t % CL (8 channels), pixel lane pl = t / CL; per channel a pivot-shifted
+// (sum, sum of squares) over the lane's pixels -> (n, sum, M2); thread j < C / sub then merges its sub-run's sub x P triples in a
+// FIXED order (deterministic).  partial[((b * nblk + blk) * nsub + j) * 2 + {0, 1}]; n = (pixels of the block) * sub.
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p, int nblk) {
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p, int nblk, int sub) {
     typedef typename Vec<T>::v8 v8;
-    extern __shared__ float lds[];   // [2][P*C]: per pixel-lane channel sums, reduced in a FIXED order (deterministic)
+    extern __shared__ float lds[];   // [P*C] sums, [P*C] M2, [P] counts
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
+    float* ls = lds;
+    float* lm = lds + P * C;
+    float* ln = lds + 2 * P * C;
     const int b = blockIdx.y, blk = blockIdx.x;
     const int ppb = (p.HW + nblk - 1) / nblk;
     const int start = blk * ppb, end = min(p.HW, start + ppb);
     const int t = threadIdx.x;
     if (t < CL * P) {
         const int cl = t % CL, pl = t / CL;
-        float s[8], q[8];
+        float s[8], q[8], pv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; pv[e] = 0.f; }
         const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
-        int pix = start + pl;
-        for (; pix + 3 * P < end; pix += 4 * P) {
-            v8 v0 = *(const v8*)(x + (size_t)pix * C);
-            v8 v1 = *(const v8*)(x + (size_t)(pix + P) * C);
-            v8 v2 = *(const v8*)(x + (size_t)(pix + 2 * P) * C);
-            v8 v3 = *(const v8*)(x + (size_t)(pix + 3 * P) * C);
+        int cnt = 0;
+        for (int pix = start + pl; pix < end; pix += P) {
+            const v8 v = *(const v8*)(x + (size_t)pix * C);
+            if (cnt == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
-                s[e] += (f0 + f1) + (f2 + f3);
-                q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+                for (int e = 0; e < 8; ++e) pv[e] = to_f32(v[e]);
             }
-        }
-        for (; pix < end; pix += P) {
-            v8 v = *(const v8*)(x + (size_t)pix * C);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float f = to_f32(v[e]); s[e] += f; q[e] += f * f; }
+            for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]) - pv[e]; s[e] += f; q[e] = __builtin_fmaf(f, f, q[e]); }
+            ++cnt;
         }
+        const float n = (float)cnt;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            lds[pl * C + cl * 8 + e] = s[e];
-            lds[P * C + pl * C + cl * 8 + e] = q[e];
+            ls[pl * C + cl * 8 + e] = __builtin_fmaf(n, pv[e], s[e]);
+            lm[pl * C + cl * 8 + e] = cnt ? fmaxf(q[e] - s[e] * s[e] / n, 0.f) : 0.f;
+        }
+        if (cl == 0) ln[pl] = n;
+    }
+    __syncthreads();
+    const int nsub = C / sub;
+    for (int j = t; j < nsub; j += GN_THREADS) {
+        float n = 0.f, s = 0.f, m2 = 0.f;
+        for (int pl = 0; pl < P; ++pl) {
+            const float np = ln[pl];
+            for (int c = j * sub; c < (j + 1) * sub; ++c) chan_merge(n, s, m2, np, ls[pl * C + c], lm[pl * C + c]);
+        }
+        float* o = p.partial + (((size_t)b * nblk + blk) * nsub + j) * 2;
+        o[0] = s; o[1] = m2;
+    }
+}
+
+// step 2: one workgroup per sample.  16 slices x 32 group lanes add up, in double, S = sum_i sum_i, Q = sum_i (M2_i + sum_i^2 / n_i),
+// N = sum_i n_i over the partials of their group (fixed order), then mean = S / N, var = (Q - S^2 / N) / N -- the between-partial term
+// in double, the within-partial terms already centred.  Source 1 covers channels [0, C1), source 2 (optional) [C1, C).
+// npart > 0: elements per partial (a producer epilogue: block rows x sub); npart == 0: the ragged blocks of gn_stats_kernel
+// ((pixels of block k) * sub with ppb = ceil(HW / nblk)).
+__global__ __launch_bounds__(GN_THREADS) void gn_table_kernel(const NormParams p) {
+    __shared__ double part_s[16][64], part_q[16][64], part_n[16][64];
+    __shared__ float mean_s[64], rstd_s[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int C = p.C, cpg = C / p.groups;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    {
+        const int g = t % 32, sl = t / 32;
+        for (int gg = g; gg < p.groups; gg += 32) {
+            double S = 0.0, Q = 0.0, N = 0.0;
+            const int c0 = gg * cpg, c1 = c0 + cpg;
+#pragma unroll 1
+            for (int src = 0; src < 2; ++src) {
+                const float* pp = src == 0 ? p.partial : p.partial2;
+                if (!pp) continue;
+                const int cb = src == 0 ? 0 : p.C1, ce = src == 0 ? p.C1 : C;          // channel range of this source
+                const int lo = max(c0, cb), hi = min(c1, ce);
+                if (lo >= hi) continue;
+                const int sub = src == 0 ? p.sub : p.sub2, nblk = src == 0 ? p.nblk : p.nblk2, npart = src == 0 ? p.npart : p.npart2;
+                const int nsub = (ce - cb) / sub;
+                const int j0 = (lo - cb) / sub, j1 = (hi - cb) / sub;
+                const int ppb = (p.HW + nblk - 1) / nblk;
+                const f2* base = (const f2*)pp + (size_t)b * nblk * nsub;
+                for (int k = sl; k < nblk; k += 16) {
+                    const double n = npart > 0 ? (double)npart : (double)(min(p.HW, (k + 1) * ppb) - k * ppb) * sub;
+                    if (n <= 0.0) continue;
+                    for (int j = j0; j < j1; ++j) {
+                        const f2 v = base[(size_t)k * nsub + j];
+                        S += (double)v[0];
+                        Q += (double)v[1] + (double)v[0] * (double)v[0] / n;
+                        N += n;
+                    }
+                }
+            }
+            part_s[sl][gg] = S; part_q[sl][gg] = Q; part_n[sl][gg] = N;
         }
     }
     __syncthreads();
     if (t < p.groups) {
-        const int cpg = C / p.groups;
-        float s = 0.f, q = 0.f;
-        for (int pl = 0; pl < P; ++pl)
-            for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += lds[pl * C + c]; q += lds[P * C + pl * C + c]; }
-        float* o = p.partial + (((size_t)b * nblk + blk) * p.groups + t) * 2;
-        o[0] = s; o[1] = q;
+        double S = 0.0, Q = 0.0, N = 0.0;
+        for (int sl = 0; sl < 16; ++sl) { S += part_s[sl][t]; Q += part_q[sl][t]; N += part_n[sl][t]; }
+        const double mean = S / N;
+        double var = (Q - S * S / N) / N;
+        if (var < 0.0) var = 0.0;
+        mean_s[t] = (float)mean;
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    float* tab = p.table + (size_t)b * C * 2;
+    for (int c = t; c < C; c += GN_THREADS) {
+        const int g = c / cpg;
+        const float gm = p.gamma ? (p.dtype_f16 ? to_f32(((const f16_t*)p.gamma)[c]) : to_f32(((const bf16_t*)p.gamma)[c])) : 1.f;
+        const float bt = p.beta ? (p.dtype_f16 ? to_f32(((const f16_t*)p.beta)[c]) : to_f32(((const bf16_t*)p.beta)[c])) : 0.f;
+        const float sc = gm * rstd_s[g];
+        f2 o = {sc, bt - mean_s[g] * sc};
+        *(f2*)(tab + (size_t)c * 2) = o;
     }
 }
 
-// pass 2: finalise statistics (double), then y = silu?(x * scale[c] + shift[c]).
+// step 3, stand-alone: y = silu?(x * scale[c] + shift[c]) with the per-sample table of step 2
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk, int nstat) {
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk) {
     typedef typename Vec<T>::v8 v8;
-    __shared__ float mean_s[64], rstd_s[64];
-    __shared__ double part_s[16][64], part_q[16][64];
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, GN_THREADS);
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
@@ -90,52 +183,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
     const int ppb = (p.HW + nblk - 1) / nblk;
     const int start = blk * ppb, end = min(p.HW, start + ppb);
     const int t = threadIdx.x;
-    {   // 16 slices x groups threads sum the per-block partials, then a fixed-order combine (deterministic)
-        const int g = t % 32, sl = t / 32;           // GN_THREADS = 512 -> 16 slices of 32 lanes
-        for (int gg = g; gg < p.groups; gg += 32) {
-            // nstat partial blocks per sample: pass 1's, or the producing conv / GEMM's (up to 512 of them: eight independent
-            // 8-B loads in flight per thread -- one dependent load per step left this prologue at ~nstat / 16 L2 latencies)
-            typedef __attribute__((ext_vector_type(2))) float f2;
-            const f2* pp = (const f2*)p.partial + ((size_t)b * nstat) * p.groups + gg;
-            double s = 0.0, q = 0.0;
-            int k = sl;
-            for (; k + 7 * 16 < nstat; k += 8 * 16) {
-                f2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(k + u * 16) * p.groups];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { s += v[u][0]; q += v[u][1]; }
-            }
-            for (; k < nstat; k += 16) { const f2 v = pp[(size_t)k * p.groups]; s += v[0]; q += v[1]; }
-            part_s[sl][gg] = s; part_q[sl][gg] = q;
-        }
-    }
-    __syncthreads();
-    if (t < p.groups) {
-        double s = 0.0, q = 0.0;
-        for (int sl = 0; sl < 16; ++sl) { s += part_s[sl][t]; q += part_q[sl][t]; }
-        const double n = (double)p.HW * (C / p.groups);
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mean_s[t] = (float)mean;
-        rstd_s[t] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
-    __syncthreads();
     if (t < CL * P) {
         const int cl = t % CL, pl = t / CL;
-        const int cpg = C / p.groups;
         float sc[8], sh[8];
-        const T* ga = (const T*)p.gamma;
-        const T* be = (const T*)p.beta;
+        {
+            const f32x4* tb = (const f32x4*)(p.table + ((size_t)b * C + cl * 8) * 2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cl * 8 + e;
-            const int g = c / cpg;
-            const float gm = ga ? to_f32(ga[c]) : 1.f;
-            const float bt = be ? to_f32(be[c]) : 0.f;
-            sc[e] = gm * rstd_s[g];
-            sh[e] = bt - mean_s[g] * sc[e];
+            for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
         }
         const T* x = (const T*)p.x + ((size_t)b * p.HW) * C + cl * 8;
         T* y = (T*)p.y + ((size_t)b * p.HW) * C + cl * 8;
@@ -143,7 +197,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
             v8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = to_f32(v[e]) * sc[e] + sh[e];
+                float f = __builtin_fmaf(to_f32(v[e]), sc[e], sh[e]);       // (the same expression as conv_halo.hip's in-kernel apply: bit-equal)
                 if (p.silu) f = silu_f(f);
                 o[e] = from_f32<T>(f);
             }
@@ -159,25 +213,51 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
     }
 }
 
-int groupnorm_launch(const NormParams& p, int dtype, hipStream_t stream) {
-    if (p.C % 8 || p.groups <= 0 || p.groups > 64 || p.C % p.groups || (p.C >> 3) > GN_THREADS) {
-        set_error("groupnorm: unsupported C=%d groups=%d", p.C, p.groups);
+// mode: IMH_GN_ALL statistics + table + apply (workspace in p.partial: partials, then the table); IMH_GN_STATS statistics only
+// (-> p.partial); IMH_GN_TABLE table from the partials of one or two producers (-> p.table); IMH_GN_APPLY apply p.table
+int groupnorm_launch(const NormParams& p0, int dtype, hipStream_t stream) {
+    NormParams p = p0;
+    if (p.C % 8 || p.groups <= 0 || p.groups > 64 || p.C % p.groups || (p.C >> 3) > GN_THREADS || p.B <= 0 || p.HW <= 0) {
+        set_error("groupnorm: unsupported B=%d HW=%d C=%d groups=%d", p.B, p.HW, p.C, p.groups);
         return IMH_ERR_SHAPE;
     }
-    if (!p.partial) { set_error("groupnorm: workspace missing"); return IMH_ERR_WORKSPACE; }
+    if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("groupnorm: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    p.dtype_f16 = dtype == IMH_DT_F16;
     const int nblk = gn_nblk(p.HW, p.C);
-    // stats_blocks > 0: `partial` already holds the (sum, sum of squares) of stats_blocks pixel blocks per sample, left behind by the
-    // epilogue of the GEMM / conv that wrote x (imh_gemm_args.gn_out): pass 1 is skipped
-    const int nstat = p.stats_blocks > 0 ? p.stats_blocks : nblk;
+    const int mode = p.mode;
+    if (mode < 0 || mode > 3) { set_error("groupnorm: unknown mode %d", mode); return IMH_ERR_ARG; }
+    const int cpg = p.C / p.groups;
+    if (mode == 0 || mode == 1) {
+        if (!p.x || !p.partial) { set_error("groupnorm: statistics need x and a partial / workspace buffer"); return p.x ? IMH_ERR_WORKSPACE : IMH_ERR_ARG; }
+        const int sub = mode == 0 ? gn_sub(p.C, p.groups) : p.sub;
+        if (sub <= 0 || p.C % sub || (mode == 0 && cpg % sub)) { set_error("groupnorm: sub-run width %d does not divide C=%d", sub, p.C); return IMH_ERR_ARG; }
+        const int P = std::max(1, GN_THREADS / (p.C >> 3));
+        const size_t lds = (2 * (size_t)p.C * P + P) * sizeof(float);
+        dim3 grid(nblk, p.B);
+        if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk, sub);
+        else hipLaunchKernelGGL((gn_stats_kernel<f16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk, sub);
+        if (mode == 1) return check_launch("gn_stats_kernel");
+        // all-in-one: the table lives behind the partials in the workspace
+        const size_t part = (size_t)p.B * nblk * (p.C / sub) * 2 * sizeof(float);
+        p.table = (float*)((unsigned char*)p.partial + ((part + 255) & ~(size_t)255));
+        p.partial2 = nullptr; p.C1 = p.C; p.sub = sub; p.nblk = nblk; p.npart = 0;
+    }
+    if (mode == 0 || mode == 2) {
+        if (!p.partial || !p.table) { set_error("groupnorm: the table step needs partials and a table buffer"); return IMH_ERR_ARG; }
+        if (!p.partial2) p.C1 = p.C;
+        const bool two = p.partial2 != nullptr;
+        if (p.sub <= 0 || p.nblk <= 0 || p.C1 <= 0 || p.C1 > p.C || p.C1 % p.sub || cpg % p.sub || (two && (p.sub2 <= 0 || p.nblk2 <= 0 || (p.C - p.C1) % p.sub2 || cpg % p.sub2 || p.C1 % p.sub2))
+            || !(p.eps > 0.f)) {
+            set_error("groupnorm table: sub-runs must tile the groups (C=%d groups=%d C1=%d sub=%d/%d nblk=%d/%d) and eps > 0", p.C, p.groups, p.C1, p.sub, p.sub2, p.nblk, p.nblk2);
+            return IMH_ERR_ARG;
+        }
+        hipLaunchKernelGGL(gn_table_kernel, dim3(p.B), dim3(GN_THREADS), 0, stream, p);
+        if (mode == 2) return check_launch("gn_table_kernel");
+    }
+    if (!p.x || !p.y || !p.table) { set_error("groupnorm: apply needs x, y and a table"); return IMH_ERR_ARG; }
     dim3 grid(nblk, p.B);
-    const size_t lds = 2 * (size_t)p.C * std::max(1, GN_THREADS / (p.C >> 3)) * sizeof(float);
-    if (dtype == IMH_DT_BF16) {
-        if (p.stats_blocks <= 0) hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
-        hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk, nstat);
-    } else if (dtype == IMH_DT_F16) {
-        if (p.stats_blocks <= 0) hipLaunchKernelGGL((gn_stats_kernel<f16_t>), grid, dim3(GN_THREADS), lds, stream, p, nblk);
-        hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk, nstat);
-    } else { set_error("groupnorm: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
+    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+    else hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
     return check_launch("groupnorm");
 }
 

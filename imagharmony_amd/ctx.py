@@ -37,6 +37,17 @@ def _read_tuning():
         return {}
 
 
+class GnStats:
+    """GroupNorm partials of ONE tensor (csrc/imh_lnstats.h gn_emit / norm.hip gn_stats_kernel): t [B, nblk, C / sub, 2] fp32 =
+    (sum, M2) per (sample, pixel block, sub-run of `sub` channels); npart = elements per partial (0: the ragged blocks of the
+    stand-alone statistics kernel).  Travels with the tensor from the launch that wrote it to every GroupNorm that reads it
+    (directly or through a channel concat)."""
+    __slots__ = ("t", "nblk", "sub", "npart", "C")
+
+    def __init__(self, t, nblk, sub, npart, C_):
+        self.t, self.nblk, self.sub, self.npart, self.C = t, int(nblk), int(sub), int(npart), int(C_)
+
+
 class Ctx:
     def __init__(self, device, dtype=torch.bfloat16, record=False, dry=False):
         """dry=True (record only): tensors may live on the CPU; the plan can be inspected (op list,
@@ -192,7 +203,7 @@ class Ctx:
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             ln=None, stats_out=False, gn_out=None, _args_only=False):
+             ln=None, stats_out=False, gn_out=None, x2=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
         ln = (s, c, eps[, stats]) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
         (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' statistics as handed
@@ -200,14 +211,24 @@ class Ctx:
         supplies them (the kernels have no in-loop E[x^2] - mean^2 form).
         stats_out=True: also return the row statistics of y for a LayerNorm-folding consumer -> (y, (tensor, slots)); they
         come from the GEMM's own epilogue when the chosen variant has one, else from a row-statistics launch over y.
-        gn_out=(groups, hw): y is a GroupNorm input of hw rows per sample -> (y, gn) with gn = (partials, blocks per sample) from
-        the epilogue for groupnorm(stats=gn), or gn = None when the chosen variant has no such epilogue."""
+        gn_out=hw (rows per sample; a (groups, hw) pair is accepted, the groups are the consumer's business): y is a GroupNorm
+        input -> (y, gn) with gn = GnStats from the epilogue, or None when the chosen variant has no such epilogue (the consumer
+        then runs gn_stats over y).
+        x2: the token operand is the column concat [x | x2] (K = x.shape[1] + x2.shape[1]; the up blocks' conv_shortcut over
+        torch.cat([hidden, skip], 1)) read from its two producers -- plain 64 / 128 tiles and the wave-specialised variants."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         M = M if M is not None else x.shape[0]
-        K = K if K is not None else x.shape[1]
+        K = K if K is not None else x.shape[1] + (x2.shape[1] if x2 is not None else 0)
         N = N if N is not None else w.shape[0]
         if x.stride(-1) != 1 or w.stride(-1) != 1:
             raise L.ImhError(f"{descr}: operands must be contiguous in K")
+        if x2 is not None:
+            self._chk(x2, descr + ".x2")
+            if x2.shape[0] != x.shape[0] or x2.stride(-1) != 1 or x.shape[1] % 64 or x2.shape[1] % 64 or x.shape[1] + x2.shape[1] != K \
+                    or x2.stride(0) != x2.shape[1] or (flags & (L.GF_LN_ROW | L.GF_LN_COL | L.GF_VT_PERM)):
+                raise L.ImhError(f"{descr}: x2 must be a dense [M, K2] block with K1, K2 multiples of 64 and K1 + K2 == K (no folded LayerNorm)")
+        if isinstance(gn_out, tuple):
+            gn_out = gn_out[1]
         n_out = N // 2 if flags & L.GF_GEGLU else N
         if out is None:
             out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
@@ -224,10 +245,16 @@ class Ctx:
         if stats_out and gn_out is not None:
             raise L.ImhError(f"{descr}: stats_out and gn_out are mutually exclusive (one consumer norm per output)")
         bm, bn, sp = cfg or self._config(M, N, K, 0, flags, ln_pre=ln_stats is not None)
+        if x2 is not None and not (bm <= 128 or bm in self._WS):
+            if cfg is not None:
+                raise L.ImhError(f"{descr}: variant {bm} does not read a two-source token operand")
+            bm, bn, sp = (128, 128, 1) if M * N >= 8192 * 640 else (64, 64, 1)
         if _args_only:
             sp = 1
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        if x2 is not None:
+            a.X2, a.Cin1 = x2.data_ptr(), x.shape[1]
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
         keep_ln = ()
         if ln is not None:           # (s, c fp32, eps[, stats]); the caller sets GF_LN_ROW / GF_LN_COL in flags
@@ -255,14 +282,14 @@ class Ctx:
         gn = self._gn_epilogue(a, gn_out) if gn_out is not None and not _args_only else None
         es = x.element_size()
         if _args_only:
-            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual) + keep_ln
+            return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual, x2) + keep_ln
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual) + keep_ln + ((st[0],) if st else ()) + ((gn[0],) if gn else ()),
+                   keep=(x, w, out, bias, rowadd, residual, x2) + keep_ln + ((st[0],) if st else ()) + ((gn.t,) if gn else ()),
                    shape=(M, N, K, 0, None),
                    epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
                             rows_per_batch=rows_per_batch, cfg=(bm, bn, sp), ln_pre=ln_stats is not None,
                             ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None,
-                            gn_out=(gn[1], gn_out[0], gn_out[1]) if gn else None))
+                            gn_out=(gn.nblk, gn_out) if gn else None, x2=x.shape[1] if x2 is not None else 0))
         if own_stats:
             self.free(ln_stats[0])
         if stats_out:
@@ -273,20 +300,19 @@ class Ctx:
             return out, gn
         return out
 
-    def _gn_epilogue(self, a, gn_out):
+    def _gn_epilogue(self, a, hw):
         """GroupNorm partials from the launch's epilogue (imh_gemm_args.gn_out) if its variant and shape have one: fills the
-        fields of a and returns (partials [B, blocks, groups, 2] fp32, blocks per sample), else None"""
-        groups, hw = gn_out
+        fields of a and returns the GnStats of the output ([B, blocks, N / 10, 2] fp32), else None"""
         rows = self.lib.imh_gemm_gn_block_rows(a.bm, a.bn)
         halo = a.bm in self._HALO
-        if (rows <= 0 or a.splits != 1 or a.N % groups or a.N // groups not in (10, 20, 40) or hw % rows or a.M % hw
+        if (rows <= 0 or a.splits != 1 or a.N % 10 or hw % rows or a.M % hw
                 or a.N % (a.bn if halo else 80) or a.flags & ~(L.GF_ACT_SILU | L.GF_ACT_GELU)
                 or (halo and (a.Ho % (rows // 4) or a.Wo % 16))):
             return None
         nblk = hw // rows
-        t = self.new(a.M // hw, nblk, groups, 2, dtype=torch.float32)
-        a.gn_out, a.gn_nblk, a.gn_groups, a.gn_hw = t.data_ptr(), nblk, groups, hw
-        return t, nblk
+        t = self.new(a.M // hw, nblk, a.N // 10, 2, dtype=torch.float32)
+        a.gn_out, a.gn_nblk, a.gn_hw = t.data_ptr(), nblk, hw
+        return GnStats(t, nblk, 10, rows * 10, a.N)
 
     def row_stats(self, x, descr="row_stats"):
         """LayerNorm statistics of token rows x [rows, C] in the hand-over format (one slot per row): the stand-alone
@@ -326,23 +352,45 @@ class Ctx:
             self.free(own[0])
         return o1, o2
 
+    def conv_fuses_gn(self, M, N, K, stride=1, up=0, cfg=None):
+        """True when the conv3x3 launch of this shape runs on the LDS-halo kernel, which takes the GroupNorm (+ SiLU) of its input
+        (gn=...) and a two-source channel concat (x2=...) in its halo staging"""
+        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride)
+        if bm not in self._HALO or stride != 1 or up:
+            return False
+        ph = 4 if bm == 7564 else (16 if bm in (7256, 7356) else 8)
+        S = 3 if bm in (7328, 7356) else (4 if bm == 7428 else 2)
+        lds = 2 * (((ph + 2) * 18 + 7) // 8) * 8 * 128 + S * bn * 128 + (K // 9) * 8
+        return lds <= 160 * 1024
+
     def conv3x3(self, x, w, bias=None, stride=1, up=0, residual=None, rowadd=None, ldra=0, out=None, cfg=None,
-                descr="conv3x3", gn_groups=0):
+                descr="conv3x3", gn_groups=0, gn=None, x2=None):
         """x: NHWC [B, H, W, Cin]; w: packed [Cout, 9*Cin]; returns NHWC [B, Ho, Wo, Cout]; with gn_groups > 0 (the output is
-        a GroupNorm input) -> (y, gn) as gemm(gn_out=...)."""
+        a GroupNorm input) -> (y, GnStats or None) as gemm(gn_out=...).
+        gn = (table [B, Cin, 2] fp32 from gn_table(), silu): the input's GroupNorm (+ SiLU) is applied inside the kernel's halo
+        staging (diffusers ResnetBlock2D: norm -> nonlinearity -> conv in one launch); x2: the input is the channel concat
+        [x | x2].  Both need the LDS-halo variant (conv_fuses_gn)."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
-        B, H, W, Cin = x.shape
+        B, H, W, C1 = x.shape
+        Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
         Cout = w.shape[0]
         Hv, Wv = H << up, W << up
         Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
         M, N, K = B * Ho * Wo, Cout, 9 * Cin
         if not x.is_contiguous() or not w.is_contiguous() or w.shape[1] != K:
             raise L.ImhError(f"{descr}: x must be contiguous NHWC and w packed [Cout, 9*Cin]")
+        if x2 is not None:
+            self._chk(x2, descr + ".x2")
+            if tuple(x2.shape[:3]) != (B, H, W) or not x2.is_contiguous() or C1 % 64 or x2.shape[-1] % 64:
+                raise L.ImhError(f"{descr}: x2 must be contiguous NHWC over the same pixels, both channel counts multiples of 64")
         if out is None:
             out = self.new(B, Ho, Wo, Cout)
         # (the table is keyed by (M, N, K): a stride-2 conv can share its key with a stride-1 conv of another resolution /
         # batch; the LDS-halo kernel is stride-1 only -> _config falls back to the heuristic tile for that one)
         bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride)
+        if (gn is not None or x2 is not None) and not self.conv_fuses_gn(M, N, K, stride, up, cfg=(bm, bn, sp)):
+            raise L.ImhError(f"{descr}: the fused GroupNorm front end / two-source input need the LDS-halo conv3x3 (variant {bm} x {bn}, "
+                             f"stride {stride}, up {up}); apply the GroupNorm / concat as passes for this launch (Ctx.conv_fuses_gn)")
         a = L.GemmArgs()
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
@@ -353,16 +401,25 @@ class Ctx:
         a.rows_per_batch = Ho * Wo
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, 0, self.dt, 1, bm, bn
         a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
+        if x2 is not None:
+            a.X2, a.Cin1 = x2.data_ptr(), C1
+        if gn is not None:
+            tab, silu = gn
+            if tuple(tab.shape) != (B, Cin, 2) or tab.dtype != torch.float32 or not tab.is_contiguous():
+                raise L.ImhError(f"{descr}: GroupNorm table {tuple(tab.shape)} does not fit [{B}, {Cin}, 2] fp32")
+            a.gn_tab, a.gn_silu = tab.data_ptr(), int(bool(silu))
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
-        gn = self._gn_epilogue(a, (gn_groups, Ho * Wo)) if gn_groups else None
+        gs = self._gn_epilogue(a, Ho * Wo) if gn_groups else None
         es = x.element_size()
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K,
-                   nbytes=es * (B * H * W * Cin + N * K + M * N), keep=(x, w, out, bias, rowadd, residual) + ((gn[0],) if gn else ()),
+                   nbytes=es * (B * H * W * Cin + N * K + M * N),
+                   keep=(x, w, out, bias, rowadd, residual, x2) + ((gs.t,) if gs else ()) + ((gn[0],) if gn is not None else ()),
                    shape=(M, N, K, 1, (B, H, W, Cin, stride, up)),
                    epi=dict(flags=0, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
-                            rows_per_batch=Ho * Wo, cfg=(bm, bn, sp), gn_out=(gn[1], gn_groups, Ho * Wo) if gn else None))
-        return (out, gn) if gn_groups else out
+                            rows_per_batch=Ho * Wo, cfg=(bm, bn, sp), gn_out=(gs.nblk, Ho * Wo) if gs else None,
+                            gn_in=None if gn is None else int(bool(gn[1])), x2=C1 if x2 is not None else 0))
+        return (out, gs) if gn_groups else out
 
     # ------------------------------------------------------------------ attention
     def attention(self, q, k, vt, out, B, H, Lq, Lk, Lk_pad, ldq, ldk, ldvt, ldo, scale,
@@ -433,26 +490,81 @@ class Ctx:
         return out
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm", stats=None):
-        """x: [B, HW, C] (NHWC flattened).  stats = (partials, blocks per sample) left by the producing launch's epilogue
-        (gemm(gn_out=...) / conv3x3(gn_groups=...)): the statistics pass over x is skipped."""
+    def _norm_args(self, B, HW, Cc, groups, eps, silu, mode):
+        a = L.NormArgs()
+        a.B, a.HW, a.C, a.groups, a.eps, a.silu, a.dtype, a.mode = B, HW, Cc, groups, eps, int(silu), self.dt, mode
+        return a
+
+    def gn_stats(self, x, sub=10, descr="gn_stats"):
+        """stand-alone GroupNorm statistics of x [B, HW, C] (a pass over x) in the hand-over format -- for tensors whose writing
+        launch has no statistics epilogue (conv_in, split-K / ring variants)"""
         self._chk(x, descr + ".x")
         B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+        if Cc % sub:
+            raise L.ImhError(f"{descr}: sub-run width {sub} does not divide C={Cc}")
+        nblk = self.lib.imh_groupnorm_stats_blocks(HW, Cc)
+        t = self.new(B, nblk, Cc // sub, 2, dtype=torch.float32)
+        a = self._norm_args(B, HW, Cc, 1, 1.0, 0, L.GN_STATS)
+        a.x, a.partial, a.sub = x.data_ptr(), t.data_ptr(), sub
+        self._emit(L.OP_GROUPNORM, a, descr=descr, nbytes=float(x.numel() * x.element_size()), keep=(x, t))
+        return GnStats(t, nblk, sub, 0, Cc)
+
+    def gn_table(self, stats, gamma, beta, groups, eps, HW, descr="gn_table"):
+        """(scale, shift) table [B, C, 2] fp32 of a GroupNorm from the partials of its input: stats = GnStats or a list of two
+        (channel concat [a | b]: C = a.C + b.C)"""
+        srcs = list(stats) if isinstance(stats, (list, tuple)) else [stats]
+        if not 1 <= len(srcs) <= 2:
+            raise L.ImhError(f"{descr}: one or two statistics sources")
+        Cc = sum(g.C for g in srcs)
+        B = srcs[0].t.shape[0]
+        cpg = Cc // groups
+        for g in srcs:
+            if tuple(g.t.shape) != (B, g.nblk, g.C // g.sub, 2) or g.t.dtype != torch.float32 or cpg % g.sub or srcs[0].C % g.sub:
+                raise L.ImhError(f"{descr}: statistics {tuple(g.t.shape)} (sub {g.sub}) do not fit C={Cc}, groups={groups}")
+        tab = self.new(B, Cc, 2, dtype=torch.float32)
+        a = self._norm_args(B, HW, Cc, groups, eps, 0, L.GN_TABLE)
+        a.gamma, a.beta, a.table = self._p(gamma), self._p(beta), tab.data_ptr()
+        a.partial, a.nblk, a.sub, a.npart, a.C1 = srcs[0].t.data_ptr(), srcs[0].nblk, srcs[0].sub, srcs[0].npart, srcs[0].C
+        if len(srcs) == 2:
+            a.partial2, a.nblk2, a.sub2, a.npart2 = srcs[1].t.data_ptr(), srcs[1].nblk, srcs[1].sub, srcs[1].npart
+        self._emit(L.OP_GROUPNORM, a, descr=descr, keep=(gamma, beta, tab) + tuple(g.t for g in srcs))
+        return tab
+
+    def gn_apply(self, x, tab, silu, out=None, descr="gn_apply"):
+        """y = silu?(x * scale + shift) as a pass (the consumers that cannot take the table themselves: Linear layers, the
+        implicit-GEMM convs)"""
+        self._chk(x, descr + ".x")
+        B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+        if tuple(tab.shape) != (B, Cc, 2) or tab.dtype != torch.float32:
+            raise L.ImhError(f"{descr}: table {tuple(tab.shape)} does not fit [{B}, {Cc}, 2]")
         if out is None:
             out = self.new(*x.shape)
-        a = L.NormArgs()
-        a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(gamma), self._p(beta)
-        # scratch use is confined to this op's two kernels (stream order), so the shared workspace is safe
-        if stats is not None:
-            if tuple(stats[0].shape) != (B, stats[1], groups, 2) or stats[0].dtype != torch.float32:
-                raise L.ImhError(f"{descr}: statistics {tuple(stats[0].shape)} do not fit [{B}, {stats[1]}, {groups}, 2]")
-            a.partial, a.stats_blocks = stats[0].data_ptr(), int(stats[1])
-        else:
-            a.partial = self.workspace(self.lib.imh_groupnorm_workspace_bytes(B, HW, Cc, groups)).data_ptr()
-        a.B, a.HW, a.C, a.groups, a.eps, a.silu, a.dtype = B, HW, Cc, groups, eps, int(silu), self.dt
+        a = self._norm_args(B, HW, Cc, 1, 1.0, silu, L.GN_APPLY)
+        a.x, a.y, a.table = x.data_ptr(), out.data_ptr(), tab.data_ptr()
         es = x.element_size()
-        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=(2.0 if stats is not None else 3.0) * es * x.numel(),
-                   keep=(x, out, gamma, beta) + ((stats[0],) if stats is not None else ()))
+        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=4.0 * x.numel(), nbytes=2.0 * es * x.numel(), keep=(x, out, tab))
+        return out
+
+    def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm", stats=None):
+        """x: [B, HW, C] (NHWC flattened).  stats = GnStats left by the producing launch's epilogue (gemm(gn_out=...) /
+        conv3x3(gn_groups=...)) or by gn_stats(): table + apply, no statistics pass over x; None: statistics + table + apply."""
+        self._chk(x, descr + ".x")
+        B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+        if stats is not None:
+            if not isinstance(stats, GnStats) or stats.C != Cc or stats.t.shape[0] != B:
+                raise L.ImhError(f"{descr}: statistics do not fit x {tuple(x.shape)}")
+            tab = self.gn_table(stats, gamma, beta, groups, eps, HW, descr=descr + ".table")
+            y = self.gn_apply(x, tab, silu, out=out, descr=descr)
+            self.free(tab)
+            return y
+        if out is None:
+            out = self.new(*x.shape)
+        a = self._norm_args(B, HW, Cc, groups, eps, silu, L.GN_ALL)
+        a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(gamma), self._p(beta)
+        # scratch use is confined to this op's three kernels (stream order), so the shared workspace is safe
+        a.partial = self.workspace(self.lib.imh_groupnorm_workspace_bytes(B, HW, Cc, groups)).data_ptr()
+        es = x.element_size()
+        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=8.0 * x.numel(), nbytes=3.0 * es * x.numel(), keep=(x, out, gamma, beta))
         return out
 
     def layernorm(self, x, gamma, beta, eps, out=None, descr="layernorm"):

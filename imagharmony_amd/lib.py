@@ -14,6 +14,7 @@ ABI_VERSION = 6
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
+GN_ALL, GN_STATS, GN_TABLE, GN_APPLY = 0, 1, 2, 3
 (EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX,
  EW_ROW_STATS) = range(11)
 
@@ -24,7 +25,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
                 ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
                 ("ln_stats", _vp), ("ln_stats_out", _vp), ("ln_slots", _i32), ("ln_slots_out", _i32),
-                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_groups", _i32), ("gn_hw", _i32),
+                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_hw", _i32), ("gn_tab", _vp), ("gn_silu", _i32), ("X2", _vp), ("Cin1", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
@@ -60,7 +61,9 @@ class SmallAttnArgs(C.Structure):
 class NormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("partial", _vp),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("rows", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("stats_blocks", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32),
+                ("mode", _i32), ("table", _vp), ("partial2", _vp), ("nblk", _i32), ("sub", _i32), ("npart", _i32), ("C1", _i32),
+                ("nblk2", _i32), ("sub2", _i32), ("npart2", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
 
 
 class EwArgs(C.Structure):
@@ -87,6 +90,8 @@ SYMBOLS = [
     ("imh_attention_small", C.c_int, [C.POINTER(SmallAttnArgs), _vp]),
     ("imh_groupnorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_groupnorm_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("imh_groupnorm_stats_blocks", C.c_int, [C.c_int, C.c_int]),
+    ("imh_groupnorm_stats_sub", C.c_int, [C.c_int, C.c_int]),
     ("imh_layernorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_elementwise", C.c_int, [C.c_int, C.POINTER(EwArgs), _vp]),
     ("imh_plan_create", _vp, []),

@@ -43,16 +43,40 @@ FOLD_LAYERNORM = True
 # False here (IMH_LN_STATS=0, A/B) makes every consumer take its statistics from a stand-alone row-statistics launch instead.
 LN_STATS_HANDOVER = os.environ.get("IMH_LN_STATS", "1") != "0"
 # GroupNorm statistics the same way: the conv / GEMM that writes a GroupNorm input (conv1 -> norm2, conv2 / proj_out / the
-# stride-2 downsampler -> the next block's norm1 / Transformer2DModel.norm / conv_norm_out) leaves per-group (sum, sum of
-# squares) partials behind from its epilogue (imh_gemm_args.gn_out) and imh_groupnorm skips its statistics pass over the
-# tensor.  Inputs no epilogue covers (conv_in, the up path's channel concats) keep the two-pass GroupNorm.
-# False = every GroupNorm takes its own statistics (A/B; IMH_GN_STATS=0).
+# stride-2 downsampler -> the next block's norm1 / Transformer2DModel.norm / conv_norm_out, ALSO through the up path's channel
+# concats: the two producers' partials are merged) leaves (sum, M2) partials per 10-channel sub-run behind from its epilogue
+# (imh_gemm_args.gn_out); a tiny launch turns them into the per-sample (scale, shift) table of the GroupNorm.  Tensors no epilogue
+# covers (conv_in, split-K / ring variants) get theirs from one statistics pass.  False = every tensor takes the pass (A/B;
+# IMH_GN_STATS=0).
 GN_STATS_HANDOVER = os.environ.get("IMH_GN_STATS", "1") != "0"
+# ... and the GroupNorm itself -- diffusers ResnetBlock2D: norm -> SiLU -> conv -- is applied INSIDE the consuming
+# conv3x3's halo staging wherever that conv runs on the LDS-halo kernel (the 128 x 128 and 64 x 64 levels): no normalised tensor in
+# memory, and the up path's torch.cat([hidden, skip], 1) is read from its two producers by the same kernel (and by conv_shortcut's
+# GEMM): no concat pass either.  False = table + apply pass + materialised concat everywhere (A/B; IMH_GN_FUSE=0).
+GN_FUSE = os.environ.get("IMH_GN_FUSE", "1") != "0"
 
 
-def _pair(r, paired):
-    """(tensor, statistics) of an emit call that returns a pair only when asked for statistics"""
-    return r if paired else (r, None)
+class Feat:
+    """an activation travelling through the UNet with the GroupNorm partials its writing launch left behind (or None)"""
+    __slots__ = ("t", "gs")
+
+    def __init__(self, t, gs=None):
+        self.t, self.gs = t, gs
+
+    def stats(self, ctx, groups):
+        """the tensor's GroupNorm partials: the producer's, else one statistics pass (kept: skip tensors are normalised twice).
+        Sub-runs of gcd(C / groups, 10) channels tile the groups of every reader, alone or through a concat with a tensor of a
+        multiple of C channels (SDXL: 10, like the producers' epilogues)"""
+        if self.gs is None:
+            B, C_ = self.t.shape[0], self.t.shape[-1]
+            self.gs = ctx.gn_stats(self.t.view(B, -1, C_), sub=math.gcd(C_ // groups, 10))
+        return self.gs
+
+    def free(self, ctx):
+        ctx.free(self.t)
+        if self.gs is not None:
+            ctx.free(self.gs.t)
+            self.gs = None
 
 
 @dataclass
@@ -282,14 +306,16 @@ class Transformer2DModel(nn.Module):
             [BasicTransformerBlock(channels, heads, cross_attention_dim) for _ in range(n_layers)])
         self.proj_out = Linear(channels, channels)
 
-    def emit(self, ctx, x, kvs, st, gn_in=None, want_gn=False):
-        """x: NHWC [B, H, W, C] -> same shape (x is consumed).  gn_in: GroupNorm partials of x left by the launch that wrote it;
-        want_gn: also return those of the output (from proj_out's epilogue, None if its variant has none) -> (out, gn)."""
+    def emit(self, ctx, f, kvs, st):
+        """f: Feat of NHWC [B, H, W, C] (consumed) -> Feat of the same shape, with the GroupNorm partials of the output left by
+        proj_out's epilogue (None if its variant has none)."""
+        x = f.t
         B, Hh, Ww, C_ = x.shape
         L_ = Hh * Ww
         x2 = x.view(B * L_, C_)
-        n = ctx.groupnorm(x.view(B, L_, C_), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps,
-                          silu=False, descr="t2d.norm", stats=gn_in)
+        tab = ctx.gn_table(f.stats(ctx, self.groups), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps, L_, descr="t2d.norm.table")
+        n = ctx.gn_apply(x.view(B, L_, C_), tab, False, descr="t2d.norm")
+        ctx.free(tab)
         blocks = list(self.transformer_blocks)
         ho = LN_STATS_HANDOVER and bool(blocks) and blocks[0].fused(L_)
         r = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in", stats_out=ho)
@@ -299,11 +325,12 @@ class Transformer2DModel(nn.Module):
             more = ho and i + 1 < len(blocks) and blocks[i + 1].fused(L_)
             r = blk.emit(ctx, h, B, L_, kv, st, stats=stats, want_stats=more)
             h, stats = r if more else (r, None)
-        out = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out",
-                       gn_out=(self.groups, L_) if want_gn else None)
-        out, gn = out if want_gn else (out, None)
-        ctx.free(h); ctx.free(x)
-        return (out.view(B, Hh, Ww, C_), gn) if want_gn else out.view(B, Hh, Ww, C_)
+        r = ctx.gemm(h, _w(self.proj_out, ctx), bias=_b(self.proj_out, ctx), residual=x2, descr="t2d.proj_out",
+                     gn_out=L_ if GN_STATS_HANDOVER else None)
+        out, gn = r if GN_STATS_HANDOVER else (r, None)
+        ctx.free(h)
+        f.free(ctx)
+        return Feat(out.view(B, Hh, Ww, C_), gn)
 
 
 class ResnetBlock2D(nn.Module):
@@ -318,36 +345,62 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(cin, cout, 1) if cin != cout else None
         self.temb_offset = 0    # column of this block inside the stacked time_emb_proj output
 
-    def emit(self, ctx, x, st, keep_input=False, gn_in=None, want_gn=False):
-        """x: NHWC [B, H, W, Cin] -> [B, H, W, Cout]; x is consumed unless keep_input.  GroupNorm statistics travel with the
-        tensors (GN_STATS_HANDOVER): gn_in = partials of x left by the launch that wrote it (None -> norm1 takes them itself),
-        conv1's epilogue leaves norm2's, and with want_gn conv2's leaves those of the output -> (out, gn or None)."""
-        B, Hh, Ww, Cin = x.shape
+    def emit(self, ctx, f, st, skip=None, keep_input=False):
+        """f: Feat of NHWC [B, H, W, C1]; skip: Feat of the skip connection (the block's input is torch.cat([f, skip], channels),
+        diffusers UpBlock2D / CrossAttnUpBlock2D) or None -> Feat [B, H, W, Cout].  Both inputs are consumed unless keep_input.
+        GroupNorm statistics travel with the tensors (Feat.gs); where the convs run on the LDS-halo kernel, norm1 / norm2 (+ SiLU)
+        and the concat happen inside them (GN_FUSE), else as passes."""
+        x = f.t
+        B, Hh, Ww, C1 = x.shape
+        HW = Hh * Ww
+        M = B * HW
+        sk = skip.t if skip is not None else None
+        Cin = C1 + (sk.shape[-1] if sk is not None else 0)
         Cout = self.conv1.weight.shape[0]
-        n = ctx.groupnorm(x.view(B, Hh * Ww, Cin), _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups,
-                          self.norm1.eps, silu=True, descr="res.norm1", stats=gn_in).view(B, Hh, Ww, Cin)
+        want = 1 if GN_STATS_HANDOVER else 0
+        srcs = [f.stats(ctx, self.groups)] + ([skip.stats(ctx, self.groups)] if skip is not None else [])
+        tab1 = ctx.gn_table(srcs, _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups, self.norm1.eps, HW, descr="res.norm1.table")
         ra = st.temb_all[:, self.temb_offset:self.temb_offset + Cout]
-        h = ctx.conv3x3(n, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
-                        descr="res.conv1", gn_groups=self.groups if GN_STATS_HANDOVER else 0)
-        h, g2 = h if GN_STATS_HANDOVER else (h, None)
-        ctx.free(n)
-        n = ctx.groupnorm(h.view(B, Hh * Ww, Cout), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups,
-                          self.norm2.eps, silu=True, descr="res.norm2", stats=g2).view(B, Hh, Ww, Cout)
-        ctx.free(h)
-        if self.conv_shortcut is not None:
-            sc = ctx.gemm(x.view(B * Hh * Ww, Cin), self.conv_shortcut.packed(ctx), bias=_b(self.conv_shortcut, ctx),
-                          descr="res.shortcut")
+        fuse1 = GN_FUSE and ctx.conv_fuses_gn(M, Cout, 9 * Cin)
+        xc = None                       # the materialised concat, where something still needs it
+        if fuse1:
+            h = ctx.conv3x3(x, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
+                            descr="res.conv1", gn_groups=want, gn=(tab1, True), x2=sk)
         else:
-            sc = x.view(B * Hh * Ww, Cin)
-        out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2",
-                          gn_groups=self.groups if want_gn else 0)
-        out, gn = out if want_gn else (out, None)
-        ctx.free(n)
+            xc = ctx.concat(x, sk, descr="skip.concat") if sk is not None else x
+            n = ctx.gn_apply(xc.view(B, HW, Cin), tab1, True, descr="res.norm1").view(B, Hh, Ww, Cin)
+            h = ctx.conv3x3(n, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
+                            descr="res.conv1", gn_groups=want)
+            ctx.free(n)
+        ctx.free(tab1)
+        hf = Feat(*h) if want else Feat(h)
+        tab2 = ctx.gn_table(hf.stats(ctx, self.groups), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups, self.norm2.eps, HW, descr="res.norm2.table")
+        if self.conv_shortcut is not None:
+            wsc, bsc = self.conv_shortcut.packed(ctx), _b(self.conv_shortcut, ctx)
+            if sk is not None and xc is None:
+                sc = ctx.gemm(x.view(M, C1), wsc, bias=bsc, x2=sk.view(M, Cin - C1), descr="res.shortcut")
+            else:
+                sc = ctx.gemm((xc if xc is not None else x).view(M, Cin), wsc, bias=bsc, descr="res.shortcut")
+        else:
+            sc = x.view(M, Cin)
+        if GN_FUSE and ctx.conv_fuses_gn(M, Cout, 9 * Cout):
+            out = ctx.conv3x3(hf.t, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2", gn_groups=want,
+                              gn=(tab2, True))
+        else:
+            n = ctx.gn_apply(hf.t.view(B, HW, Cout), tab2, True, descr="res.norm2").view(B, Hh, Ww, Cout)
+            out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2", gn_groups=want)
+            ctx.free(n)
+        ctx.free(tab2)
+        hf.free(ctx)
         if self.conv_shortcut is not None:
             ctx.free(sc)
+        if xc is not None and sk is not None:
+            ctx.free(xc)
         if not keep_input:
-            ctx.free(x)
-        return (out, gn) if want_gn else out
+            f.free(ctx)
+            if skip is not None:
+                skip.free(ctx)
+        return Feat(*out) if want else Feat(out)
 
 
 class Downsample2D(nn.Module):
@@ -618,68 +671,55 @@ class UNet2DConditionModel(nn.Module):
                tab=st.in_scale_tab, step=st.step if st.in_scale_tab is not None else None,
                i=(S, Hl, Wl, boc[0], B, 0), f=(1.0, 0, 0, 0), descr="conv_in",
                nbytes=2.0 * B * Hl * Wl * boc[0])
-        skips = [x]
-        h = x
-        # GroupNorm statistics travel with h: hg = the partials its writing launch left for the GroupNorm that reads it next
-        # (a resnet's norm1, a Transformer2DModel's norm, conv_norm_out), None where that launch has no such epilogue
-        # (conv_in, channel concats)
+        h = Feat(x)                      # (conv_in has no statistics epilogue: Feat.stats() takes one pass, shared by both readers)
+        skips = [h]
         ho = GN_STATS_HANDOVER
-        G = cfg.norm_num_groups
-        hg = None
+        kv_of = lambda t2d: [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))]
         # -- down --
         for bi, blk in enumerate(self.down_blocks):
             for i, r in enumerate(blk.resnets):
                 ctx.tag = 10 + bi
-                h, hg = _pair(r.emit(ctx, h, st, keep_input=True, gn_in=hg, want_gn=ho), ho)      # inputs are skip tensors: keep
+                h = r.emit(ctx, h, st, keep_input=True)       # inputs are skip tensors: keep
                 if blk.has_attn:
                     ctx.tag = 20 + bi
-                    t2d = blk.attentions[i]
-                    kvs = [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))]
-                    h, hg = _pair(t2d.emit(ctx, h, kvs, st, gn_in=hg, want_gn=ho), ho)
+                    h = blk.attentions[i].emit(ctx, h, kv_of(blk.attentions[i]), st)
                 skips.append(h)
             if blk.downsamplers is not None:
                 ctx.tag = 10 + bi
                 d = blk.downsamplers[0].conv
-                h, hg = _pair(ctx.conv3x3(h, d.packed(ctx), bias=_b(d, ctx), stride=2, descr="downsample", gn_groups=G if ho else 0), ho)
+                r_ = ctx.conv3x3(h.t, d.packed(ctx), bias=_b(d, ctx), stride=2, descr="downsample", gn_groups=1 if ho else 0)
+                h = Feat(*r_) if ho else Feat(r_)
                 skips.append(h)
         # -- mid --
         ctx.tag = 30
         mb = self.mid_block
-        h, hg = _pair(mb.resnets[0].emit(ctx, h, st, keep_input=True, gn_in=hg, want_gn=ho), ho)
-        t2d = mb.attentions[0]
+        h = mb.resnets[0].emit(ctx, h, st, keep_input=True)
         ctx.tag = 31
-        h, hg = _pair(t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st,
-                               gn_in=hg, want_gn=ho), ho)
+        h = mb.attentions[0].emit(ctx, h, kv_of(mb.attentions[0]), st)
         ctx.tag = 30
-        h = mb.resnets[1].emit(ctx, h, st, gn_in=hg)
-        hg = None
+        h = mb.resnets[1].emit(ctx, h, st)
         # -- up --
         for bi, blk in enumerate(self.up_blocks):
             for i, r in enumerate(blk.resnets):
                 ctx.tag = 40 + bi
-                sk = skips.pop()
-                hc = ctx.concat(h, sk, descr="skip.concat")
-                ctx.free(h); ctx.free(sk)
-                last = bi + 1 == len(self.up_blocks) and i + 1 == len(blk.resnets)
-                want = ho and (blk.has_attn or last)            # read next by a t2d.norm / conv_norm_out (else by a concat)
-                h, hg = _pair(r.emit(ctx, hc, st, want_gn=want), want)
+                h = r.emit(ctx, h, st, skip=skips.pop())      # torch.cat([hidden, skip], 1) is read from its two producers
                 if blk.has_attn:
                     ctx.tag = 50 + bi
-                    t2d = blk.attentions[i]
-                    h = t2d.emit(ctx, h, [st.kv[self._pname(t2d, k)] for k in range(len(t2d.transformer_blocks))], st, gn_in=hg)
-                    hg = None
+                    h = blk.attentions[i].emit(ctx, h, kv_of(blk.attentions[i]), st)
             if blk.upsamplers is not None:
                 ctx.tag = 40 + bi
                 u = blk.upsamplers[0].conv
-                hu = ctx.conv3x3(h, u.packed(ctx), bias=_b(u, ctx), up=1, descr="upsample")
-                ctx.free(h)
-                h, hg = hu, None
+                r_ = ctx.conv3x3(h.t, u.packed(ctx), bias=_b(u, ctx), up=1, descr="upsample", gn_groups=1 if ho else 0)
+                h.free(ctx)
+                h = Feat(*r_) if ho else Feat(r_)
         # -- out --
         ctx.tag = 60
-        Bh, Hh, Ww, C0 = h.shape
-        n = ctx.groupnorm(h.view(B, Hh * Ww, C0), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx),
-                          cfg.norm_num_groups, cfg.norm_eps, silu=True, descr="conv_norm_out", stats=hg).view(B, Hh, Ww, C0)
-        ctx.free(h)
+        Bh, Hh, Ww, C0 = h.t.shape
+        tab = ctx.gn_table(h.stats(ctx, cfg.norm_num_groups), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx), cfg.norm_num_groups, cfg.norm_eps,
+                           Hh * Ww, descr="conv_norm_out.table")
+        n = ctx.gn_apply(h.t.view(B, Hh * Ww, C0), tab, True, descr="conv_norm_out").view(B, Hh, Ww, C0)
+        ctx.free(tab)
+        h.free(ctx)
         out = ctx.conv3x3(n, self.conv_out.packed(ctx), bias=_b(self.conv_out, ctx), descr="conv_out")
         ctx.free(n)
         ctx.tag = 0

@@ -102,15 +102,27 @@ typedef struct imh_gemm_args {
     const float* ln_stats;
     float* ln_stats_out;
     int32_t ln_slots, ln_slots_out;
-    /* GroupNorm partials of THIS launch's output, for the imh_groupnorm that reads it (diffusers ResnetBlock2D.norm2 after
-     * conv1, the next block's norm1 / Transformer2DModel.norm after conv2 / conv_shortcut + residual): (sum, sum of squares)
-     * of the values as rounded to the output dtype, gn_out[((b * gn_nblk + blk) * gn_groups + g) * 2 + {0, 1}] fp32, one
-     * partial block per imh_gemm_gn_block_rows(bm, bn) consecutive rows (pixels) of a sample; gn_hw = rows per sample,
-     * gn_nblk = gn_hw / block rows.  Hand the buffer to imh_norm_args.partial with stats_blocks = gn_nblk.  NULL -> none.
-     * Variants with this epilogue: the wave-specialised ones at bn = 160 and the LDS-halo conv3x3; N / gn_groups must be
-     * 10, 20 or 40 (SDXL: 320 / 640 / 1280 channels, 32 groups); no split-K, GEGLU, V^T permutation, fp32 output, LN. */
+    /* GroupNorm partials of THIS launch's output, for the GroupNorm that reads it (diffusers ResnetBlock2D.norm2 after conv1, the
+     * next block's norm1 / Transformer2DModel.norm after conv2 / conv_shortcut + residual; also through a channel concat): one
+     * (sum, M2) pair -- M2 = squared deviations from the partial's own mean, values as rounded to the output dtype -- per
+     * (sample, pixel block, sub-run of 10 consecutive output channels): gn_out[((b * gn_nblk + blk) * (N / 10) + n / 10) * 2 + {0, 1}]
+     * fp32, one block per imh_gemm_gn_block_rows(bm, bn) consecutive rows (pixels) of a sample (10 * that many elements per
+     * partial); gn_hw = rows per sample, gn_nblk = gn_hw / block rows.  Hand the buffer to imh_groupnorm (mode IMH_GN_TABLE:
+     * partial / nblk = gn_nblk / sub = 10 / npart = 10 * block rows).  NULL -> none.  Variants with this epilogue: the
+     * wave-specialised ones at bn = 160 and the LDS-halo conv3x3; N % 10 == 0; no split-K, GEGLU, V^T permutation, fp32 output, LN. */
     float* gn_out;
-    int32_t gn_nblk, gn_groups, gn_hw;
+    int32_t gn_nblk, gn_hw;
+    /* LDS-halo conv3x3 only (variants 7128 / 7564 / 7256 / 73xx / 74xx, stride 1, no upsampling): the ResnetBlock2D front end
+     * norm -> SiLU -> conv in one launch.  gn_tab = the (scale, shift) table of the INPUT's GroupNorm, [B][Cin][2] fp32 as written
+     * by imh_groupnorm(mode IMH_GN_TABLE): every staged input pixel becomes silu?(x * scale + shift) inside the kernel (padding
+     * stays zero: the conv pads the normalised tensor); the normalised activation never exists in memory.  NULL -> plain conv. */
+    const float* gn_tab;
+    int32_t gn_silu;
+    /* LDS-halo conv3x3 only: the input is the channel concat [X | X2] (torch.cat([hidden, skip], 1) of the up blocks) read from
+     * its two producers: channels [0, Cin1) from X (pixel stride Cin1), [Cin1, Cin) from X2 (pixel stride Cin - Cin1); both
+     * multiples of 64.  X2 == NULL -> one source. */
+    const void* X2;
+    int32_t Cin1;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;
@@ -238,10 +250,23 @@ int imh_attention_small(const imh_small_attn_args* a, void* stream);
 
 /* ---- normalisation ----------------------------------------------------------------------
  * imh_groupnorm: GroupNorm(groups) over NHWC x[B, HW, C] with optional fused SiLU
- *   (diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out).
+ *   (diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out), in three steps that can run
+ *   together or apart (torch.nn.GroupNorm semantics: fp32 statistics, biased variance; Welford / Chan merges, never
+ *   E[x^2] - mean^2):
+ *     statistics  (sum, M2) partials per (sample, pixel block, sub-run of `sub` consecutive channels) -- from a pass over x
+ *                 (IMH_GN_STATS) or from the epilogue of the launch that wrote x (imh_gemm_args.gn_out, sub = 10)
+ *     table       (scale, shift)[b][c] = (gamma[c] * rstd, beta[c] - mean * gamma[c] * rstd) from the partials of ONE or TWO producers
+ *                 (the second covers channels [C1, C): the other half of a channel concat)                      (IMH_GN_TABLE)
+ *     apply       y = silu?(x * scale + shift) as a pass (IMH_GN_APPLY) -- or inside the consuming conv3x3 (imh_gemm_args.gn_tab)
  * imh_layernorm: LayerNorm over the last dim of x[rows, C] (BasicTransformerBlock.norm1/2/3,
  *   ip_adapter.py:39, resampler.py:15,42,43,104, train.py:238).  gamma/beta may be NULL.
  */
+enum imh_gn_mode {
+    IMH_GN_ALL = 0,     /* statistics + table + apply; `partial` = workspace of imh_groupnorm_workspace_bytes() */
+    IMH_GN_STATS = 1,   /* x -> partial[B][imh_groupnorm_stats_blocks(HW, C)][C / sub][2]; sub must divide C / groups of every consumer */
+    IMH_GN_TABLE = 2,   /* partial (+ partial2) -> table[B][C][2] */
+    IMH_GN_APPLY = 3    /* x, table -> y */
+};
 typedef struct imh_norm_args {
     const void* x;
     void* y;
@@ -253,15 +278,22 @@ typedef struct imh_norm_args {
     float eps;
     int32_t silu;
     int32_t dtype;
-    /* imh_groupnorm only: > 0 -> `partial` already holds that many (sum, sum of squares) blocks per sample, written by the
-     * producing launch's gn_out epilogue (imh_gemm_args), and the statistics pass over x is skipped; 0 -> taken here */
-    int32_t stats_blocks;
+    /* imh_groupnorm only */
+    int32_t mode;            /* enum imh_gn_mode */
+    float* table;
+    const float* partial2;   /* IMH_GN_TABLE: second producer's partials or NULL */
+    int32_t nblk, sub, npart;    /* source 1: partial blocks per sample, channels per sub-run, elements per partial (0 = the ragged
+                                  * blocks of IMH_GN_STATS: (pixels of block k) * sub with ceil(HW / nblk) pixels per block) */
+    int32_t C1;                  /* channels covered by source 1 (ignored without partial2) */
+    int32_t nblk2, sub2, npart2;
     const void* pf_ptr;    /* tail prefetch of the next launch's weights (cache hint) */
     uint32_t pf_bytes;
 } imh_norm_args;
 
 int imh_groupnorm(const imh_norm_args* a, void* stream);
 size_t imh_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int imh_groupnorm_stats_blocks(int HW, int C);       /* pixel blocks per sample of IMH_GN_STATS */
+int imh_groupnorm_stats_sub(int C, int groups);      /* the sub-run width IMH_GN_ALL uses: 10 when it divides C / groups, else C / groups */
 int imh_layernorm(const imh_norm_args* a, void* stream);
 
 /* ---- small fused elementwise kernels (see csrc/elementwise.hip for the field meaning) ---- */

@@ -1,13 +1,19 @@
-"""GPU: the GroupNorm-statistics hand-over (imh_gemm_args.gn_out / imh_norm_args.stats_blocks) -- the conv / GEMM that writes
-a GroupNorm input leaves per-(sample, pixel block, group) (sum, sum of squares) partials behind from its epilogue and
-imh_groupnorm skips its statistics pass.  Reference math: diffusers ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm,
-conv_norm_out = torch GroupNorm(32) (+ SiLU), here F.group_norm in fp32 on the values as stored."""
+"""GPU: GroupNorm as statistics -> table -> apply (csrc/norm.hip, imh_lnstats.h gn_emit, conv_halo.hip):
+  * the conv / GEMM that writes a GroupNorm input leaves (sum, M2) partials per (sample, pixel block, 10-channel sub-run) behind
+    from its epilogue (imh_gemm_args.gn_out); tensors no epilogue covers get them from one statistics pass (IMH_GN_STATS);
+  * IMH_GN_TABLE merges the partials of one or TWO producers (channel concat) into the per-sample (scale, shift) table;
+  * the table is applied by a pass (IMH_GN_APPLY) or INSIDE the consuming LDS-halo conv3x3 (imh_gemm_args.gn_tab), which also reads
+    a two-source channel concat (X2).
+Reference math: diffusers ResnetBlock2D norm1 -> SiLU -> conv1 / norm2 -> SiLU -> conv2, Transformer2DModel.norm, conv_norm_out =
+torch GroupNorm(32) (+ SiLU) (+ Conv2d) (call site ip_adapter/custom_pipelines.py:338-345), here
+F.group_norm / F.conv2d in fp32 on the values as stored."""
 import ctypes as C
 
 import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import rel_rms
 from test_gpu_ops import DTYPES, L, assert_close, ctx_for, rnd  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -19,40 +25,43 @@ def pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-def _ref_partials(y, B, hw, nblk, groups, tile=None):
-    """y [B * hw, C] as stored -> [B, nblk, groups, 2]; tile = (Ho, Wo, ph, pw, waves): pixel blocks are the waves' rows of an
-    LDS-halo patch (ph x pw pixels, wave w holds rows w * ph / waves ...), else consecutive runs of hw / nblk rows"""
-    C = y.shape[1]
-    f = y.float().view(B, hw, groups, C // groups)
+def _ref_partials(y, B, hw, nblk, sub, tile=None):
+    """y [B * hw, C] as stored -> [B, nblk, C / sub, 2] = (sum, M2 about the partial's own mean) in fp64; tile = (Ho, Wo, ph, pw,
+    waves): pixel blocks are the waves' rows of an LDS-halo patch (ph x pw pixels, wave w holds rows w * ph / waves ...), else
+    consecutive runs of hw / nblk rows"""
+    C_ = y.shape[1]
+    f = y.double().view(B, hw, C_ // sub, sub)
     if tile is None:
-        f = f.view(B, nblk, hw // nblk, groups, C // groups)
+        f = f.view(B, nblk, hw // nblk, C_ // sub, sub)
     else:
         Ho, Wo, ph, pw, waves = tile
-        f = f.view(B, Ho // ph, waves, ph // waves, Wo // pw, pw, groups, C // groups).permute(0, 1, 4, 2, 3, 5, 6, 7)
-        f = f.reshape(B, nblk, (ph // waves) * pw, groups, C // groups)
-    return torch.stack([f.sum(dim=(2, 4)), f.pow(2).sum(dim=(2, 4))], dim=-1)
+        f = f.view(B, Ho // ph, waves, ph // waves, Wo // pw, pw, C_ // sub, sub).permute(0, 1, 4, 2, 3, 5, 6, 7)
+        f = f.reshape(B, nblk, (ph // waves) * pw, C_ // sub, sub)
+    s = f.sum(dim=(2, 4))
+    mean = f.mean(dim=(2, 4), keepdim=True)
+    return torch.stack([s, (f - mean).pow(2).sum(dim=(2, 4))], dim=-1).float()
 
 
-def _check_partials(gn, ref, y, rows, what):
-    st, nblk = gn
-    assert st.shape == ref.shape, (st.shape, ref.shape)
-    cnt = rows * (y.shape[1] // G)
+def _check_partials(gs, ref, y, what):
+    assert gs.t.shape == ref.shape, (gs.t.shape, ref.shape)
+    n = gs.npart
     amax = y.float().abs().max().item()
-    e0 = (st[..., 0] - ref[..., 0].to(st.device)).abs().max().item()
-    e1 = (st[..., 1] - ref[..., 1].to(st.device)).abs().max().item()
-    assert e0 <= 4e-6 * cnt * amax and e1 <= 4e-6 * cnt * amax * amax, f"{what}: sum err {e0:.3e}, sumsq err {e1:.3e} (count {cnt}, amax {amax:.3e})"
+    ref = ref.to(gs.t.device)
+    e0 = (gs.t[..., 0] - ref[..., 0]).abs().max().item()
+    # M2 is centred: its error scale is the spread of the values (var), not their square -- relative to the largest partial
+    e1 = ((gs.t[..., 1] - ref[..., 1]).abs() / (ref[..., 1] + 1e-6 * n * amax * amax)).max().item()
+    assert e0 <= 4e-6 * n * amax and e1 <= 2e-4, f"{what}: sum err {e0:.3e} (count {n}, amax {amax:.3e}), M2 rel err {e1:.3e}"
 
 
-def _check_groupnorm(ctx, y, B, hw, gn, dtype, what):
-    """imh_groupnorm fed with the handed-over partials == its own two-pass result (same reduction tree apart from the block
-    order) and == torch"""
-    C = y.shape[1]
-    gamma, beta = rnd(C, dtype=dtype, seed=11) + 1.0, rnd(C, dtype=dtype, seed=12)
-    a = ctx.groupnorm(y.view(B, hw, C), gamma, beta, G, 1e-5, True, stats=gn)
-    b = ctx.groupnorm(y.view(B, hw, C), gamma, beta, G, 1e-5, True)
-    ref = F.silu(F.group_norm(y.float().view(B, hw, C).transpose(1, 2), G, gamma.float(), beta.float(), 1e-5)).transpose(1, 2)
+def _check_groupnorm(ctx, y, B, hw, gs, dtype, what):
+    """imh_groupnorm fed with the handed-over partials == its own statistics pass == torch"""
+    C_ = y.shape[1]
+    gamma, beta = rnd(C_, dtype=dtype, seed=11) + 1.0, rnd(C_, dtype=dtype, seed=12)
+    a = ctx.groupnorm(y.view(B, hw, C_), gamma, beta, G, 1e-5, True, stats=gs)
+    b = ctx.groupnorm(y.view(B, hw, C_), gamma, beta, G, 1e-5, True)
+    ref = F.silu(F.group_norm(y.float().view(B, hw, C_).transpose(1, 2), G, gamma.float(), beta.float(), 1e-5)).transpose(1, 2)
     assert_close(a, ref, dtype, what + " groupnorm(stats)")
-    assert (a.float() - b.float()).abs().max().item() <= (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(1.0, ref.abs().max().item()), what
+    assert_close(b, ref, dtype, what + " groupnorm(own pass)")
     ctx.free(a); ctx.free(b)
 
 
@@ -67,26 +76,28 @@ def test_gemm_epilogue_leaves_groupnorm_partials(L, dtype, cfg, rows):
         x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
         bias, res = rnd(N, dtype=dtype, seed=5), (rnd(M, N, dtype=dtype, seed=6) * 1.5 + 0.5).contiguous()
         for residual in (res, None):
-            y, gn = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, gn_out=(G, hw))
-            assert gn is not None and gn[1] == hw // rows
+            y, gs = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, gn_out=hw)
+            assert gs is not None and gs.nblk == hw // rows and gs.sub == 10 and gs.npart == 10 * rows and gs.C == N
             ref = x.float() @ w.float().t() + bias.float() + (residual.float() if residual is not None else 0.0)
             assert_close(y, ref, dtype, f"gemm {cfg} {(M, N, K)}")
             what = f"GroupNorm partials {cfg} {(B, hw, N, K)} residual={residual is not None}"
-            _check_partials(gn, _ref_partials(y, B, hw, gn[1], G), y, rows, what)
-            _check_groupnorm(ctx, y, B, hw, gn, dtype, what)
-            y2, gn2 = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, gn_out=(G, hw))
-            assert torch.equal(y2, y) and torch.equal(gn2[0], gn[0])
-            for t in (y, gn[0], y2, gn2[0]):
+            _check_partials(gs, _ref_partials(y, B, hw, gs.nblk, 10), y, what)
+            _check_groupnorm(ctx, y, B, hw, gs, dtype, what)
+            y2, gs2 = ctx.gemm(x, w, bias=bias, residual=residual, cfg=cfg, gn_out=hw)
+            assert torch.equal(y2, y) and torch.equal(gs2.t, gs.t)
+            for t in (y, gs.t, y2, gs2.t):
                 ctx.free(t)
 
 
+HALO_CASES = [dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 320, 1), ph=8), dict(B=2, H=16, W=16, Cin=64, Cout=640, cfg=(7128, 320, 1), ph=8),
+              dict(B=1, H=16, W=16, Cin=64, Cout=1280, cfg=(7128, 320, 1), ph=8), dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7128, 160, 1), ph=8),
+              dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7328, 160, 1), ph=8), dict(B=1, H=24, W=16, Cin=192, Cout=1280, cfg=(7428, 160, 1), ph=8),
+              dict(B=2, H=32, W=32, Cin=128, Cout=320, cfg=(7256, 160, 1), ph=16), dict(B=1, H=16, W=32, Cin=64, Cout=640, cfg=(7356, 160, 1), ph=16),
+              dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1), ph=4), dict(B=1, H=12, W=32, Cin=64, Cout=640, cfg=(7564, 320, 1), ph=4)]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 320, 1), ph=8), dict(B=2, H=16, W=16, Cin=64, Cout=640, cfg=(7128, 320, 1), ph=8),
-                                  dict(B=1, H=16, W=16, Cin=64, Cout=1280, cfg=(7128, 320, 1), ph=8), dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7128, 160, 1), ph=8),
-                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7328, 160, 1), ph=8), dict(B=1, H=24, W=16, Cin=192, Cout=1280, cfg=(7428, 160, 1), ph=8),
-                                  dict(B=2, H=32, W=32, Cin=128, Cout=320, cfg=(7256, 160, 1), ph=16), dict(B=1, H=16, W=32, Cin=64, Cout=640, cfg=(7356, 160, 1), ph=16),
-                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1), ph=4), dict(B=1, H=12, W=32, Cin=64, Cout=640, cfg=(7564, 320, 1), ph=4),
-                                  dict(B=2, H=8, W=8, Cin=64, Cout=320, up=1, cfg=(7128, 320, 1), ph=8)])
+@pytest.mark.parametrize("case", HALO_CASES + [dict(B=2, H=8, W=8, Cin=64, Cout=320, up=1, cfg=(7128, 320, 1), ph=8)])
 def test_halo_conv_epilogue_leaves_groupnorm_partials(L, dtype, case):
     """conv1 (bias + time-embedding row) and conv2 (bias + residual) on every LDS-halo variant; a wave's patch rows are a block"""
     ctx = ctx_for(dtype)
@@ -106,14 +117,14 @@ def test_halo_conv_epilogue_leaves_groupnorm_partials(L, dtype, case):
     conv = F.conv2d(xin, w4.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(B, hw, Cout)
     for kw, ref in ((dict(rowadd=temb, ldra=temb.stride(0)), conv + temb.float()[:, None, :]),
                     (dict(residual=res), conv + res.float().view(B, hw, Cout))):
-        y, gn = ctx.conv3x3(x, pack_conv(w4), bias=bias, up=up, cfg=cfg, gn_groups=G, **kw)
-        assert gn is not None and gn[1] == hw // rows, (gn, hw, rows)
+        y, gs = ctx.conv3x3(x, pack_conv(w4), bias=bias, up=up, cfg=cfg, gn_groups=G, **kw)
+        assert gs is not None and gs.nblk == hw // rows, (gs, hw, rows)
         y2 = y.view(B * hw, Cout)
         assert_close(y2, ref.reshape(B * hw, Cout), dtype, f"conv {case}")
         what = f"GroupNorm partials {case} {list(kw)}"
-        _check_partials(gn, _ref_partials(y2, B, hw, gn[1], G, tile=(Ho, Wo, ph, 16, 4)), y2, rows, what)
-        _check_groupnorm(ctx, y2, B, hw, gn, dtype, what)
-        ctx.free(y); ctx.free(gn[0])
+        _check_partials(gs, _ref_partials(y2, B, hw, gs.nblk, 10, tile=(Ho, Wo, ph, 16, 4)), y2, what)
+        _check_groupnorm(ctx, y2, B, hw, gs, dtype, what)
+        ctx.free(y); ctx.free(gs.t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -129,62 +140,228 @@ def test_ws_conv_epilogue_and_fallbacks(L, dtype):
     res = (rnd(B * hw, Cout, dtype=dtype, seed=6) * 1.5 + 0.5).contiguous()
     conv = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(B * hw, Cout)
     for cfg in ((2464, 160, 1), (24128, 160, 1), (23256, 160, 1), (22128, 160, 1)):
-        y, gn = ctx.conv3x3(x, pack_conv(w4), bias=bias, residual=res, cfg=cfg, gn_groups=G)
+        y, gs = ctx.conv3x3(x, pack_conv(w4), bias=bias, residual=res, cfg=cfg, gn_groups=G)
         rows = ctx.lib.imh_gemm_gn_block_rows(cfg[0], cfg[1])
-        assert gn is not None and gn[1] == hw // rows
+        assert gs is not None and gs.nblk == hw // rows
         y2 = y.view(B * hw, Cout)
         assert_close(y2, conv + res.float(), dtype, f"ws conv {cfg}")
-        _check_partials(gn, _ref_partials(y2, B, hw, gn[1], G), y2, rows, f"ws conv {cfg}")
-        _check_groupnorm(ctx, y2, B, hw, gn, dtype, f"ws conv {cfg}")
-        ctx.free(y); ctx.free(gn[0])
-    # no epilogue: plain tiles, split-K, channel counts off the 10 / 20 / 40 grid, ragged patches
-    y, gn = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=(128, 128, 1), gn_groups=G)
-    assert gn is None
-    y, gn = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=(2464, 160, 2), gn_groups=G)
-    assert gn is None
+        _check_partials(gs, _ref_partials(y2, B, hw, gs.nblk, 10), y2, f"ws conv {cfg}")
+        _check_groupnorm(ctx, y2, B, hw, gs, dtype, f"ws conv {cfg}")
+        ctx.free(y); ctx.free(gs.t)
+    # no epilogue: plain tiles, split-K, ragged patches
+    y, gs = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=(128, 128, 1), gn_groups=G)
+    assert gs is None
+    y, gs = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=(2464, 160, 2), gn_groups=G)
+    assert gs is None
     xs = rnd(1, 12, 20, 64, dtype=dtype, seed=1)
     ws = rnd(320, 64, 3, 3, dtype=dtype, seed=2)
-    y, gn = ctx.conv3x3(xs, pack_conv(ws), cfg=(7128, 320, 1), gn_groups=G)
-    assert gn is None
+    y, gs = ctx.conv3x3(xs, pack_conv(ws), cfg=(7128, 320, 1), gn_groups=G)
+    assert gs is None
     a = L.GemmArgs()
     xg, wg = rnd(256, 128, dtype=dtype, seed=1), rnd(320, 128, dtype=dtype, seed=2)
     out = torch.empty(256, 320, dtype=dtype, device=DEV)
-    part = torch.zeros(1, 8, G, 2, dtype=torch.float32, device=DEV)
+    part = torch.zeros(1, 8, 32, 2, dtype=torch.float32, device=DEV)
     a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy = xg.data_ptr(), wg.data_ptr(), out.data_ptr(), 256, 320, 128, 128, 128, 320
     a.splits, a.dtype, a.bm, a.bn = 1, ctx.dt, 128, 128
-    a.gn_out, a.gn_nblk, a.gn_groups, a.gn_hw = part.data_ptr(), 8, G, 256
+    a.gn_out, a.gn_nblk, a.gn_hw = part.data_ptr(), 8, 256
     assert ctx.lib.imh_gemm(C.byref(a), ctx.stream()) != 0 and b"gn_out" in ctx.lib.imh_last_error()
     a.bm, a.bn, a.gn_nblk = 2464, 160, 4           # wrong block count for 32-row blocks
     assert ctx.lib.imh_gemm(C.byref(a), ctx.stream()) != 0
     a.gn_nblk = 8
     assert ctx.lib.imh_gemm(C.byref(a), ctx.stream()) == 0
     torch.cuda.synchronize()
-    _check_partials((part, 8), _ref_partials(out, 1, 256, 8, G), out, 32, "raw C-ABI launch")
+    from imagharmony_amd.ctx import GnStats
+    _check_partials(GnStats(part, 8, 10, 320, 320), _ref_partials(out, 1, 256, 8, 10), out, "raw C-ABI launch")
 
 
-def test_fullsize_forward_with_and_without_the_handover_agree(L):
-    """the 1024^2 CFG-2 SDXL forward (BASELINE.json configs[1] shapes, seeded random weights): GroupNorm statistics from the
-    producers' epilogues vs every GroupNorm's own pass -- same result to the bf16 noise floor of this net, and most GroupNorms are covered"""
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C_,sub", [(2, 1024, 320, 10), (1, 4096, 640, 10), (2, 300, 1280, 10), (2, 256, 960, 10), (1, 1000, 128, 4), (2, 64, 512, 16)])
+def test_statistics_pass_and_table(L, dtype, B, HW, C_, sub):
+    """IMH_GN_STATS partials (ragged pixel blocks) against fp64, and the table they make against torch's GroupNorm statistics"""
+    ctx = ctx_for(dtype)
+    x = (rnd(B, HW, C_, dtype=dtype, seed=1) * 1.7 + 0.3).contiguous()
+    gs = ctx.gn_stats(x, sub=sub)
+    nblk = gs.nblk
+    ppb = (HW + nblk - 1) // nblk
+    ref = torch.zeros(B, nblk, C_ // sub, 2, dtype=torch.float64)
+    xd = x.double().cpu().view(B, HW, C_ // sub, sub)
+    for k in range(nblk):
+        blk = xd[:, k * ppb:min(HW, (k + 1) * ppb)]
+        if blk.shape[1] == 0:
+            continue
+        ref[:, k, :, 0] = blk.sum(dim=(1, 3))
+        ref[:, k, :, 1] = (blk - blk.mean(dim=(1, 3), keepdim=True)).pow(2).sum(dim=(1, 3))
+    got = gs.t.double().cpu()
+    assert (got[..., 0] - ref[..., 0]).abs().max() <= 4e-6 * ppb * sub * x.float().abs().max().item()
+    assert ((got[..., 1] - ref[..., 1]).abs() / (ref[..., 1] + 1e-3)).max() <= 3e-4
+    gamma, beta = rnd(C_, dtype=dtype, seed=11) + 1.0, rnd(C_, dtype=dtype, seed=12)
+    tab = ctx.gn_table(gs, gamma, beta, G, 1e-5, HW)
+    xg = x.double().cpu().view(B, HW, G, C_ // G)
+    mean, var = xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    sc = gamma.double().cpu()[None] * rstd.repeat_interleave(C_ // G, 1)
+    sh = beta.double().cpu()[None] - mean.repeat_interleave(C_ // G, 1) * sc
+    t = tab.double().cpu()
+    assert (t[..., 0] - sc).abs().max() <= 2e-5 * sc.abs().max() and (t[..., 1] - sh).abs().max() <= 2e-5 * (sh.abs().max() + sc.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_large_common_offset_groupnorm(L, dtype):
+    """x = 50 + N(0, 0.1) per element with a per-channel offset, as stored -- |mean| = 400-500 sigma.  Partials are
+    pivot-shifted (sum, M2) pairs merged by Chan's formula: statistics from a producer's epilogue, from the statistics pass, and the
+    all-in-one imh_groupnorm all match torch's two-pass GroupNorm on the stored values; one constant (zero-variance) group stays finite."""
+    ctx = ctx_for(dtype)
+    B, HW, C_ = 2, 1024, 320
+    g = torch.Generator().manual_seed(5)
+    x = (50.0 + 0.1 * torch.randn(B, HW, C_, generator=g) + 0.05 * torch.randn(1, 1, C_, generator=g)).to(dtype).to(DEV).contiguous()
+    x[:, :, 310:320] = 50.0                         # group 31: constant
+    gamma, beta = rnd(C_, dtype=dtype, seed=11) + 1.0, rnd(C_, dtype=dtype, seed=12)
+    ref = F.silu(F.group_norm(x.float().transpose(1, 2), G, gamma.float(), beta.float(), 1e-5)).transpose(1, 2)
+    # producer epilogue: y = 0 @ W + residual(x) through the wave-specialised kernel
+    z, wz = torch.zeros(B * HW, 64, dtype=dtype, device=DEV), torch.zeros(C_, 64, dtype=dtype, device=DEV)
+    xx, gs = ctx.gemm(z, wz, residual=x.view(B * HW, C_), cfg=(2464, 160, 1), gn_out=HW)
+    assert torch.equal(xx.view(B, HW, C_), x) and gs is not None
+    outs = {"epilogue": ctx.groupnorm(x, gamma, beta, G, 1e-5, True, stats=gs),
+            "pass": ctx.groupnorm(x, gamma, beta, G, 1e-5, True, stats=ctx.gn_stats(x)),
+            "all-in-one": ctx.groupnorm(x, gamma, beta, G, 1e-5, True)}
+    for k, y in outs.items():
+        assert torch.isfinite(y.float()).all(), k
+        # the normalised values are O(1); the stored dtype resolves 0.25 (bf16) / 0.03 (fp16) at 50, i.e. the INPUT carries the error,
+        # the statistics must not add to it: compare against torch on the same stored values
+        r = rel_rms(y[:, :, :310], ref[:, :, :310])
+        assert r < (1.5e-2 if dtype == torch.bfloat16 else 2e-3), f"{k}: rel-rms {r:.3e}"
+        assert (y[:, :, 310:].float() - ref[:, :, 310:]).abs().max() < 0.05, k      # zero variance: silu(beta)
+
+
+def _gn_conv_ref(x, gamma, beta, w4, bias, silu=True):
+    """F.group_norm -> SiLU -> F.conv2d in fp32; the normalised tensor is rounded to the storage dtype like the kernel's staged halo"""
+    B, H, W, C_ = x.shape
+    n = F.group_norm(x.float().permute(0, 3, 1, 2), G, gamma.float(), beta.float(), 1e-5)
+    if silu:
+        n = F.silu(n)
+    n = n.to(x.dtype).float()
+    return F.conv2d(n, w4.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(B=2, H=16, W=32, Cin=320, Cout=320, cfg=(7128, 320, 1)), dict(B=2, H=16, W=16, Cin=640, Cout=640, cfg=(7128, 160, 1)),
+                                  dict(B=2, H=32, W=32, Cin=320, Cout=320, cfg=(7256, 160, 1)), dict(B=1, H=16, W=32, Cin=640, Cout=320, cfg=(7356, 160, 1)),
+                                  dict(B=2, H=16, W=16, Cin=320, Cout=640, cfg=(7328, 160, 1)), dict(B=1, H=24, W=16, Cin=960, Cout=320, cfg=(7428, 160, 1)),
+                                  dict(B=2, H=20, W=24, Cin=320, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=12, W=32, Cin=640, Cout=640, cfg=(7564, 320, 1)),
+                                  dict(B=2, H=13, W=19, Cin=320, Cout=320, cfg=(7128, 160, 1))])
+def test_conv_with_fused_groupnorm_silu(L, dtype, case):
+    """ResnetBlock2D's norm -> SiLU -> conv in ONE launch on every LDS-halo variant (aligned and ragged images: the padding pixels
+    must stay zero AFTER the normalisation), statistics from the producer-format pass, against torch; bitwise repeatable; the
+    same table through the stand-alone apply + plain conv gives the same result to rounding"""
+    ctx = ctx_for(dtype)
+    B, H, W, Cin, Cout, cfg = case["B"], case["H"], case["W"], case["Cin"], case["Cout"], case["cfg"]
+    x = (rnd(B, H, W, Cin, dtype=dtype, seed=1) * 1.3 + 0.4).contiguous()
+    w4 = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, dtype=dtype, seed=3)
+    gamma, beta = rnd(Cin, dtype=dtype, seed=11) * 0.2 + 1.0, rnd(Cin, dtype=dtype, seed=12) * 0.3
+    assert ctx.conv_fuses_gn(B * H * W, Cout, 9 * Cin, cfg=cfg)
+    tab = ctx.gn_table(ctx.gn_stats(x.view(B, H * W, Cin)), gamma, beta, G, 1e-5, H * W)
+    for silu in (True, False):
+        ref = _gn_conv_ref(x, gamma, beta, w4, bias, silu)
+        y = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, silu)).view(B * H * W, Cout)
+        assert_close(y, ref, dtype, f"fused GroupNorm{'+SiLU' if silu else ''} conv {case}", k=6.0)
+        for _ in range(2):
+            assert torch.equal(ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, silu)).view(B * H * W, Cout), y)
+        n = ctx.gn_apply(x.view(B, H * W, Cin), tab, silu).view(B, H, W, Cin)
+        y2 = ctx.conv3x3(n, pack_conv(w4), bias=bias, cfg=cfg).view(B * H * W, Cout)
+        assert torch.equal(y2, y), "in-kernel apply and the apply pass round the same values"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(B=2, H=16, W=16, C1=640, C2=320, Cout=640, cfg=(7128, 160, 1)), dict(B=2, H=16, W=32, C1=320, C2=320, Cout=320, cfg=(7256, 160, 1)),
+                                  dict(B=1, H=16, W=16, C1=1280, C2=640, Cout=640, cfg=(7128, 160, 1)), dict(B=2, H=16, W=16, C1=640, C2=320, Cout=320, cfg=(7128, 320, 1))])
+def test_conv_over_a_two_source_concat_with_fused_groupnorm(L, dtype, case):
+    """the up blocks' resnet: norm1(torch.cat([hidden, skip], 1)) -> SiLU -> conv1 with the concat read from its two producers and
+    the GroupNorm statistics merged from the two tensors' partials (groups straddle the seam: 960 / 32 = 30, 1920 / 32 = 60 channels
+    per group) -- against torch on the materialised concat; and conv_shortcut's GEMM over the same two sources"""
+    ctx = ctx_for(dtype)
+    B, H, W, C1, C2, Cout, cfg = case["B"], case["H"], case["W"], case["C1"], case["C2"], case["Cout"], case["cfg"]
+    Cin = C1 + C2
+    a = (rnd(B, H, W, C1, dtype=dtype, seed=1) * 1.2 + 0.3).contiguous()
+    b = (rnd(B, H, W, C2, dtype=dtype, seed=2) * 0.7 - 0.2).contiguous()
+    xc = torch.cat([a, b], -1)
+    w4 = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=3, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, dtype=dtype, seed=4)
+    gamma, beta = rnd(Cin, dtype=dtype, seed=11) * 0.2 + 1.0, rnd(Cin, dtype=dtype, seed=12) * 0.3
+    ga, gb = ctx.gn_stats(a.view(B, H * W, C1)), ctx.gn_stats(b.view(B, H * W, C2))
+    tab = ctx.gn_table([ga, gb], gamma, beta, G, 1e-5, H * W)
+    tab_ref = ctx.gn_table(ctx.gn_stats(xc.view(B, H * W, Cin)), gamma, beta, G, 1e-5, H * W)
+    assert (tab - tab_ref).abs().max().item() <= 2e-5 * tab_ref.abs().max().item(), "two-producer table == table of the concat"
+    ref = _gn_conv_ref(xc, gamma, beta, w4, bias)
+    y = ctx.conv3x3(a, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, True), x2=b).view(B * H * W, Cout)
+    assert_close(y, ref, dtype, f"two-source fused GroupNorm conv {case}", k=6.0)
+    y1 = ctx.conv3x3(xc, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, True)).view(B * H * W, Cout)
+    assert torch.equal(y, y1), "two sources == the materialised concat, bit for bit"
+    # plain two-source conv (no GroupNorm) and the shortcut GEMM
+    y0 = ctx.conv3x3(a, pack_conv(w4), bias=bias, cfg=cfg, x2=b)
+    assert torch.equal(y0, ctx.conv3x3(xc, pack_conv(w4), bias=bias, cfg=cfg))
+    wsc = rnd(Cout, Cin, dtype=dtype, seed=7, scale=Cin ** -0.5)
+    M = B * H * W
+    for gcfg in ((128, 64, 1), (64, 64, 1), (128, 128, 1), (2464, 160, 1), (1464, 160, 1), (24128, 160, 1), (23256, 160, 1)):
+        if gcfg[0] > 128 and Cout % 160:
+            continue
+        s2 = ctx.gemm(a.view(M, C1), wsc, bias=bias, x2=b.view(M, C2), cfg=gcfg)
+        s1 = ctx.gemm(xc.view(M, Cin), wsc, bias=bias, cfg=gcfg)
+        assert torch.equal(s1, s2), f"two-source GEMM {gcfg}"
+        assert_close(s2, xc.view(M, Cin).float() @ wsc.float().t() + bias.float(), dtype, f"shortcut GEMM {gcfg}")
+    with pytest.raises(L.ImhError, match="two-source"):
+        ctx.gemm(a.view(M, C1), wsc, bias=bias, x2=b.view(M, C2), cfg=(9128, 320, 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_groupnorm_conv_on_large_mean_input(L, dtype):
+    """the fused front end on x = 50 + N(0, 0.1): statistics never go through E[x^2] - mean^2, so the conv of the normalised tensor
+    matches torch's to the precision the stored input allows"""
+    ctx = ctx_for(dtype)
+    B, H, W, Cin, Cout = 2, 16, 16, 320, 320
+    g = torch.Generator().manual_seed(3)
+    x = (50.0 + 0.1 * torch.randn(B, H, W, Cin, generator=g)).to(dtype).to(DEV).contiguous()
+    w4 = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, dtype=dtype, seed=3)
+    gamma, beta = rnd(Cin, dtype=dtype, seed=11) * 0.2 + 1.0, rnd(Cin, dtype=dtype, seed=12) * 0.3
+    tab = ctx.gn_table(ctx.gn_stats(x.view(B, H * W, Cin)), gamma, beta, G, 1e-5, H * W)
+    y = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=(7128, 160, 1), gn=(tab, True)).view(B * H * W, Cout)
+    ref = _gn_conv_ref(x, gamma, beta, w4, bias)
+    r = rel_rms(y, ref)
+    assert torch.isfinite(y.float()).all() and r < (2e-2 if dtype == torch.bfloat16 else 3e-3), f"rel-rms {r:.3e}"
+
+
+def test_fullsize_forward_fused_and_unfused_groupnorm_agree(L):
+    """the 1024^2 CFG-2 SDXL forward (BASELINE.json configs[1] shapes, seeded random weights) in three configurations: the default
+    (statistics from the producers' epilogues, GroupNorm + SiLU + concat inside the LDS-halo convs), table + apply passes +
+    materialised concats (IMH_GN_FUSE=0), and every tensor's own statistics pass (IMH_GN_STATS=0) -- same result to the bf16 noise
+    floor of this net; in the default no apply pass precedes a ResBlock conv of the 128 x 128 / 64 x 64 levels"""
     from imagharmony_amd import unet as U
     from tools.sweep import build_unet, record
     dtype = torch.bfloat16
     u = build_unet(dtype)
-    outs, covered = {}, {}
-    old = U.GN_STATS_HANDOVER
+    outs, info = {}, {}
+    old = (U.GN_STATS_HANDOVER, U.GN_FUSE)
     try:
-        for flag in (True, False):
-            U.GN_STATS_HANDOVER = flag
+        for name, (ho, fuse) in dict(default=(True, True), unfused=(True, False), own_stats=(False, False)).items():
+            U.GN_STATS_HANDOVER, U.GN_FUSE = ho, fuse
             rec, out, st = record(u, dtype, 128, S=1)
             rec.run()
             torch.cuda.synchronize()
-            outs[flag] = out.float().clone()
-            covered[flag] = sum(1 for t in rec.tags if t[6] and t[6].get("gn_out"))
+            outs[name] = out.float().clone()
+            d = [t[2] for t in rec.tags]
+            info[name] = dict(ops=len(d), apply=sum(1 for x in d if x in ("res.norm1", "res.norm2")), concat=d.count("skip.concat"),
+                              stats=d.count("gn_stats"), fused=sum(1 for t in rec.tags if t[6] and t[6].get("gn_in") is not None),
+                              producers=sum(1 for t in rec.tags if t[6] and t[6].get("gn_out")))
     finally:
-        U.GN_STATS_HANDOVER = old
-    rel = ((outs[True] - outs[False]).pow(2).mean().sqrt() / outs[False].pow(2).mean().sqrt()).item()
-    print(f"GroupNorm hand-over: {covered[True]} producing launches, rel-rms between the two forwards {rel:.3e}")
-    assert covered[False] == 0 and covered[True] >= 30, covered
-    # two bf16 forwards of this seeded random-weight UNet that differ by ANY rounding-level change sit 1.35e-2 apart
-    # (profiles/r03_forward_ab_*.json: rel_rms_vs_first of every such pair); measured here 1.43e-2.  Parity proper of the default
-    # (hand-over) path is test_gpu_parity_fullsize.py against the fp32 oracle.
-    assert torch.isfinite(outs[True]).all() and rel <= 3e-2, rel
+        U.GN_STATS_HANDOVER, U.GN_FUSE = old
+    print("GroupNorm configurations:", info)
+    assert info["default"]["fused"] == 20 and info["default"]["apply"] == 14 and info["default"]["concat"] == 3 and info["default"]["stats"] <= 4
+    assert info["unfused"]["fused"] == 0 and info["unfused"]["apply"] == 34 and info["unfused"]["concat"] == 9
+    assert info["own_stats"]["producers"] == 0 and info["default"]["producers"] >= 40
+    for k in ("unfused", "own_stats"):
+        rel = rel_rms(outs["default"], outs[k])
+        print(f"default vs {k}: rel-rms {rel:.3e}")
+        # two bf16 forwards of this seeded random-weight UNet that differ by ANY rounding-level change sit 1.35e-2 apart
+        # (profiles/r03_forward_ab_*.json); parity proper of the default path is test_gpu_parity_fullsize.py against the fp32 oracle
+        assert torch.isfinite(outs[k]).all() and rel <= 3e-2, (k, rel)

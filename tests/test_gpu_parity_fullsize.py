@@ -93,7 +93,7 @@ def test_full_sdxl_forward_matches_cpu_oracle(sdxl_pair):
 # (8 sigma in bf16, 32 sigma in fp16: at larger offsets the storage dtype itself erases the signal -- bf16 resolves 0.06 at 8,
 # fp16 0.03 at 32).  Bounds = ~2x measured; the offset costs precision in the STORED stream, not in the statistics.
 OFFSET = {torch.bfloat16: 8.0, torch.float16: 32.0}
-TOL_FWD_OFFSET = {torch.bfloat16: 6e-2, torch.float16: 1.2e-2}
+TOL_FWD_OFFSET = {torch.bfloat16: 3.5e-2, torch.float16: 4.5e-3}      # measured 1.72e-2 / 2.19e-3 (profiles/r04_parity.json)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -355,9 +355,19 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
         if conv:
             B, H, W, Cin, stride, up = geom
             x = _rnd((B, H, W, Cin), dtype, 1)
-            y = ctx.conv3x3(x, w, bias=bias, stride=stride, up=up, residual=residual, rowadd=rowadd, ldra=N if rowadd is not None else 0,
-                            cfg=(bm, bn, sp), descr=descr)
-            xin = x.float().permute(0, 3, 1, 2)
+            kwx, xf = {}, x.float()
+            if epi.get("gn_in") is not None:      # the ResnetBlock2D front end inside the launch: a per-sample (scale, shift) table
+                g = torch.Generator().manual_seed(21)
+                tab = torch.stack([1 + 0.2 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], -1).to(DEV).contiguous()
+                kwx["gn"] = (tab, bool(epi["gn_in"]))
+                xf = xf * tab[:, None, None, :, 0] + tab[:, None, None, :, 1]
+                xf = (F.silu(xf) if epi["gn_in"] else xf).to(dtype).float()      # the staged halo holds the rounded normalised values
+            xa = x
+            if epi.get("x2"):                     # torch.cat([hidden, skip], 1) read from its two producers
+                xa, kwx["x2"] = x[..., :epi["x2"]].contiguous(), x[..., epi["x2"]:].contiguous()
+            y = ctx.conv3x3(xa, w, bias=bias, stride=stride, up=up, residual=residual, rowadd=rowadd, ldra=N if rowadd is not None else 0,
+                            cfg=(bm, bn, sp), descr=descr, **kwx)
+            xin = xf.permute(0, 3, 1, 2)
             if up:
                 xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
             w4 = w.float().view(N, 3, 3, Cin).permute(0, 3, 1, 2)
@@ -377,8 +387,9 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
                 _close(y, _ref_epilogue(xn @ w.float().t(), epi, bias, residual, rowadd, L), dtype, f"{descr} {shape} {epi}", k=6.0)
             else:
                 assert not epi["flags"] & L.GF_LN_COL
-                y = ctx.gemm(x, w, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
-                             flags=epi["flags"], cfg=(bm, bn, sp), descr=descr, stats_out=bool(epi.get("stats_out")))
+                xa, x2 = (x[:, :epi["x2"]].contiguous(), x[:, epi["x2"]:].contiguous()) if epi.get("x2") else (x, None)
+                y = ctx.gemm(xa, w, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
+                             flags=epi["flags"], cfg=(bm, bn, sp), descr=descr, stats_out=bool(epi.get("stats_out")), x2=x2)
                 if epi.get("stats_out"):       # the launches that leave LayerNorm statistics behind: check them as stored
                     y, (st, slots) = y
                     want = ref_row_stats(y.float(), slots).to(DEV)

@@ -302,37 +302,63 @@ def test_folded_layernorm_launches_only_get_variants_that_implement_it():
 
 
 def test_groupnorm_statistics_handover_host_logic():
-    """host logic of the GroupNorm-statistics hand-over (Ctx._gn_epilogue): a producing launch gets gn_out only when its tile
-    variant has the epilogue AND the shape fits it (10 / 20 / 40 channels per group, whole pixel blocks, no split-K); the
-    consumer's imh_norm_args then carries the producer's buffer and block count, else it keeps its own statistics pass"""
+    """host logic of the GroupNorm hand-over (Ctx._gn_epilogue / gn_table / conv3x3(gn=..., x2=...)): a producing launch gets gn_out
+    only when its tile variant has the epilogue AND the shape fits it (N % 10 == 0, whole pixel blocks, no split-K); the table op
+    carries one or two producers' buffers; the fused front end and the two-source input are only handed to LDS-halo launches"""
     from imagharmony_amd import lib as L
-    from imagharmony_amd.ctx import Ctx
+    from imagharmony_amd.ctx import Ctx, GnStats
     ctx = Ctx("cpu", torch.bfloat16, record=True, dry=True)
     bf = torch.bfloat16
     x, w = torch.zeros(2, 32, 32, 64, dtype=bf), torch.zeros(320, 9 * 64, dtype=bf)
     for cfg, rows in (((7128, 320, 1), 32), ((7564, 160, 1), 16), ((7256, 160, 1), 64), ((2464, 160, 1), 32), ((23256, 160, 1), 64),
                       ((128, 128, 1), 0), ((2464, 160, 2), 0), ((24128, 128, 1), 0)):
         assert ctx.lib.imh_gemm_gn_block_rows(cfg[0], cfg[1]) == (rows if cfg != (2464, 160, 2) else 32)
-        y, gn = ctx.conv3x3(x, w, cfg=cfg, gn_groups=32)
+        y, gs = ctx.conv3x3(x, w, cfg=cfg, gn_groups=32)
         epi = ctx.tags[-1][6]
         if rows:
-            assert gn is not None and gn[1] == 1024 // rows and tuple(gn[0].shape) == (2, 1024 // rows, 32, 2) and gn[0].dtype == torch.float32
-            assert epi["gn_out"] == (1024 // rows, 32, 1024)
-            n = ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True, stats=gn)
-            a = ctx._ops[-1][1]
-            assert a.stats_blocks == gn[1] and a.partial == gn[0].data_ptr()
+            assert isinstance(gs, GnStats) and gs.nblk == 1024 // rows and tuple(gs.t.shape) == (2, 1024 // rows, 32, 2) and gs.t.dtype == torch.float32
+            assert (gs.sub, gs.npart, gs.C) == (10, 10 * rows, 320) and epi["gn_out"] == (1024 // rows, 1024)
+            n0 = len(ctx.tags)
+            ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True, stats=gs)
+            t_op, a_op = ctx._ops[-2][1], ctx._ops[-1][1]               # table, then apply: no statistics pass
+            assert [t[2] for t in ctx.tags[n0:]] == ["groupnorm.table", "groupnorm"]
+            assert (t_op.mode, t_op.partial, t_op.nblk, t_op.sub, t_op.npart) == (L.GN_TABLE, gs.t.data_ptr(), gs.nblk, 10, 10 * rows)
+            assert a_op.mode == L.GN_APPLY and a_op.table == t_op.table and a_op.silu == 1
         else:
-            assert gn is None and epi["gn_out"] is None
+            assert gs is None and epi["gn_out"] is None
             ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True)
-            assert ctx._ops[-1][1].stats_blocks == 0
-    # shapes off the grid: 12 channels per group, a patch grid that does not tile the image, rows per sample not a block multiple
+            assert ctx._ops[-1][1].mode == L.GN_ALL
+    # shapes off the grid: N not a multiple of 10, a patch grid that does not tile the image, rows per sample not a block multiple
     assert ctx.conv3x3(x, torch.zeros(384, 9 * 64, dtype=bf), cfg=(7128, 160, 1), gn_groups=32)[1] is None
     assert ctx.conv3x3(torch.zeros(1, 12, 20, 64, dtype=bf), w, cfg=(7128, 320, 1), gn_groups=32)[1] is None
     xg, wg = torch.zeros(2 * 48, 64, dtype=bf), torch.zeros(320, 64, dtype=bf)
     assert ctx.gemm(xg, wg, cfg=(23256, 160, 1), gn_out=(32, 48))[1] is None
-    assert ctx.gemm(torch.zeros(512, 64, dtype=bf), wg, cfg=(23256, 160, 1), gn_out=(32, 256))[1][1] == 4
+    assert ctx.gemm(torch.zeros(512, 64, dtype=bf), wg, cfg=(23256, 160, 1), gn_out=256)[1].nblk == 4
     with pytest.raises(L.ImhError, match="statistics"):
-        ctx.groupnorm(torch.zeros(2, 1024, 320, dtype=bf), None, None, 32, 1e-5, True, stats=(torch.zeros(2, 8, 16, 2), 8))
+        ctx.groupnorm(torch.zeros(2, 1024, 320, dtype=bf), None, None, 32, 1e-5, True, stats=GnStats(torch.zeros(2, 8, 16, 2), 8, 10, 320, 160))
+    # two producers (channel concat 640 + 320 -> 30 channels per group) -> one table; the fused conv reads both sources
+    a_, b_ = torch.zeros(2, 32, 32, 640, dtype=bf), torch.zeros(2, 32, 32, 320, dtype=bf)
+    ga, gb = ctx.gn_stats(a_.view(2, 1024, 640)), ctx.gn_stats(b_.view(2, 1024, 320))
+    tab = ctx.gn_table([ga, gb], None, None, 32, 1e-5, 1024)
+    t_op = ctx._ops[-1][1]
+    assert tuple(tab.shape) == (2, 960, 2) and (t_op.C, t_op.C1, t_op.partial2, t_op.sub2, t_op.npart, t_op.npart2) == (960, 640, gb.t.data_ptr(), 10, 0, 0)
+    w9 = torch.zeros(640, 9 * 960, dtype=bf)
+    assert ctx.conv_fuses_gn(2048, 640, 9 * 960, cfg=(7128, 160, 1)) and not ctx.conv_fuses_gn(2048, 640, 9 * 960, cfg=(2464, 160, 1))
+    assert not ctx.conv_fuses_gn(2048, 640, 9 * 960, stride=2, cfg=(7128, 160, 1))
+    ctx.conv3x3(a_, w9, cfg=(7128, 160, 1), gn=(tab, True), x2=b_)
+    c_op = ctx._ops[-1][1]
+    assert (c_op.X, c_op.X2, c_op.Cin, c_op.Cin1, c_op.gn_tab, c_op.gn_silu) == (a_.data_ptr(), b_.data_ptr(), 960, 640, tab.data_ptr(), 1)
+    with pytest.raises(L.ImhError, match="LDS-halo"):
+        ctx.conv3x3(a_, w9, cfg=(2464, 160, 1), gn=(tab, True), x2=b_)
+    with pytest.raises(L.ImhError, match="table"):
+        ctx.conv3x3(a_, w9, cfg=(7128, 160, 1), gn=(torch.zeros(2, 640, 2), True), x2=b_)
+    # the shortcut GEMM over the same two sources; a variant that cannot read them is replaced (or refused when explicit)
+    wsc = torch.zeros(640, 960, dtype=bf)
+    ctx.tuning[(2048, 640, 960, 0)] = (9128, 320, 1)
+    g_op = ctx.gemm(a_.view(2048, 640), wsc, x2=b_.view(2048, 320), _args_only=True)[0]
+    assert (g_op.K, g_op.Cin1, g_op.X2) == (960, 640, b_.data_ptr()) and g_op.bm <= 128
+    ctx.tuning[(2048, 640, 960, 0)] = (24128, 160, 1)
+    assert ctx.gemm(a_.view(2048, 640), wsc, x2=b_.view(2048, 320), _args_only=True)[0].bm == 24128
 
 
 def test_derived_weight_caches_follow_in_place_updates():

@@ -1,6 +1,6 @@
 """GPU tool: interleaved A/B of the attention kernels' variants on the SDXL shapes (one process, rounds interleaved, median and
 min per variant; guide rule 24).
-  self-attention  imh_debug_set(4, m): 1 in-order key loop, 2 software-pipelined key loop
+  self-attention  imh_debug_set(4, m): 1 in-order key loop, 3 software-pipelined key loop, 5 key-split workgroups
   fused cross     imh_debug_set(3, m): 1 one head per workgroup; 2 / 3 / 4 two heads, 0 / 2 / 4 producer waves, resident key tiles;
                   6 / 7 / 8 the same without the resident key tiles
 Usage: python tools/attn_ab.py [--rounds 7] > gpurun_out/attn_ab.json"""
@@ -65,16 +65,16 @@ def main():
         vt = make_vt(v, Lq)
         o = torch.empty(B * Lq, C_, device=DEV, dtype=dtype)
         rec = plan_of(lambda c: c.attention(qk[:, :C_], qk[:, C_:], vt, o, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125), dtype, a.reps)
-        res, outs = {1: [], 2: [], 3: []}, {}
+        res, outs = {1: [], 3: [], 5: []}, {}
         for r in range(a.rounds):
-            for m in (1, 2, 3):
+            for m in (1, 3, 5):
                 lib.imh_debug_set(4, m)
                 res[m].append(gpu_time(rec, a.reps))
                 if r == 0:
                     outs[m] = o.float().clone()
         lib.imh_debug_set(4, 0)
         fl = 4.0 * B * H * Lq * Lq * 64
-        diff = max(float((outs[1] - outs[2]).abs().max()), float((outs[1] - outs[3]).abs().max()))
+        diff = max(float((outs[1] - outs[3]).abs().max()), float((outs[1] - outs[5]).abs().max()))
         key = f"self B={B} H={H} L={Lq}"
         out[key] = {f"mode{m}": dict(us_median=statistics.median(t), us_min=min(t), tflops=fl / statistics.median(t) / 1e6) for m, t in res.items()}
         out[key]["max_abs_diff_between_modes"] = diff
@@ -97,7 +97,7 @@ def main():
         kk, vv = make_k(k, 128), make_vt(v, 128)
         o = torch.empty(B * Lq, C_, device=DEV, dtype=dtype)
         rec = plan_of(lambda c: c.cross_attention(x, wg, kk, vv, o, B, H, Lq, 77, 128, C_, B * 128, 0.125, ln=(s_, c_, 1e-5, st), **kw), dtype, a.reps)
-        modes = (1, 2, 3, 4, 6, 7, 8)
+        modes = (1, 3, 4)
         res, outs = {m: [] for m in modes}, {}
         for r in range(a.rounds):
             for m in modes:

@@ -4,6 +4,8 @@ in interleaved rounds: per-op HIP-event times (min over rounds, summed by op fam
 plan (median over rounds).  Knobs per configuration:
     ln_stats   unet.LN_STATS_HANDOVER (LayerNorm statistics handed over from the producing GEMM's epilogue)
     gn_stats   unet.GN_STATS_HANDOVER (GroupNorm statistics likewise)
+    gn_fuse    unet.GN_FUSE (GroupNorm + SiLU + channel concat inside the LDS-halo convs)
+    attn       imh_debug_set(4, mode): self-attention key loop
     xattn      imh_debug_set(3, mode): 1 one head per workgroup, 2 / 3 / 4 two heads with 0 / 2 / 4 producer waves
     tuning     {"M,N,K,conv[,1]": [bm, bn, splits]} overrides on top of tuning.json
 Usage: python tools/forward_ab.py [--rounds 5] [--configs name1,name2,...] [--stacked S] > gpurun_out/forward_ab.json"""
@@ -25,65 +27,27 @@ from imagharmony_amd.ctx import _load_tuning                           # noqa: E
 from tools.sweep import DEV, build_unet, record                        # noqa: E402
 
 CONFIGS = collections.OrderedDict([
-    ("r02", dict(ln_stats=False, xattn=1)),
-    ("stats", dict(ln_stats=True, xattn=1)),
-    ("stats_x2", dict(ln_stats=True, xattn=2)),
-    ("stats_x3", dict(ln_stats=True, xattn=3)),
-    ("stats_x4", dict(ln_stats=True, xattn=4)),
-    ("stats_x3_geglu128", dict(ln_stats=True, xattn=3, tuning={"2048,10240,1280,0,1": [128, 128, 1], "8192,5120,640,0,1": [128, 128, 1]})),
-    ("stats_x3_lin640_24128", dict(ln_stats=True, xattn=3, tuning={"8192,640,640,0": [24128, 160, 1]})),
-    # round-3 session C: attention key loop (attn: imh_debug_set key 4) and the resident-key-tile cross-attention
-    ("x1_a1", dict(xattn=1, attn=1)),
-    ("x3_a1", dict(xattn=3, attn=1)),
-    ("x4_a1", dict(xattn=4, attn=1)),
-    ("x7_a1", dict(xattn=7, attn=1)),
-    ("x3_a2", dict(xattn=3, attn=2)),
-    ("x4_a2", dict(xattn=4, attn=2)),
-    ("x4_a2_lin640", dict(xattn=4, attn=2, tuning={"8192,640,640,0": [24128, 160, 1]})),
-    # session D: wave-specialised projection pair of self-attention (dual_ws), in-loop vs handed-over statistics for the
-    # fused cross-attention (xstats)
-    ("d_base", dict(xattn=1, attn=1, dual_ws=False, xstats=True)),
-    ("d_xloop", dict(xattn=1, attn=1, dual_ws=False, xstats=False)),
-    ("d_dualws", dict(xattn=1, attn=1, dual_ws=True, xstats=False)),
-    ("d_dualws_pipe", dict(xattn=1, attn=2, dual_ws=True, xstats=False)),
-    ("d_all_lin640", dict(xattn=1, attn=2, dual_ws=True, xstats=False, tuning={"8192,640,640,0": [24128, 160, 1]})),
-    # session H: persistent two-tile GEGLU kernel (33256), weight rings of the LDS-halo conv (7328 / 7428 x 160)
-    ("h_base", dict()),
-    ("h_conv64_s3", dict(tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
-    ("h_conv64_s4", dict(tuning={f"8192,640,{k},1": [7428, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
-    ("h_conv128_s3", dict(tuning={f"32768,320,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640)})),
-    ("h_conv128_s4", dict(tuning={f"32768,320,{k},1": [7428, 160, 1] for k in (2880, 5760, 8640)})),
-    ("i_conv128_p16", dict(tuning={f"32768,320,{k},1": [7256, 160, 1] for k in (2880, 5760, 8640)})),
-    ("i_conv128_p16_s3", dict(tuning={f"32768,320,{k},1": [7356, 160, 1] for k in (2880, 5760, 8640)})),
-    # session J: GroupNorm statistics from the producing conv / GEMM epilogue (gn_stats)
-    ("j_gn_off", dict(gn_stats=False)),
-    ("j_gn_on", dict(gn_stats=True)),
-    # session K (--stacked 4): the S = 4 table; GEGLU with handed-over statistics on 128 x 128 instead of 256 x 160 ws
-    # session L: 128 x 160 wave-specialised tiles at TWO workgroups per CU (22128: two-slot rings, 4 consumer + 2 producer waves)
-    ("l_base", dict()),
-    ("l_geglu", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1], "8192,5120,640,0,1": [22128, 160, 1]})),
-    ("l_geglu32", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1]})),
-    ("l_all", dict(tuning={"2048,10240,1280,0,1": [22128, 160, 1], "8192,5120,640,0,1": [22128, 160, 1], "8192,640,640,0": [22128, 160, 1],
-                           "8192,640,2560,0": [22128, 160, 1]})),
-    # session M: XCD partition forced for every GEMM (imh_debug_set key 2: 2..5 = (8,1) (4,2) (2,4) (1,8); 0 = cost model)
-    ("m_auto", dict()),
-    ("m_xcd81", dict(xcd=2)),
-    ("m_xcd42", dict(xcd=3)),
-    ("m_xcd24", dict(xcd=4)),
-    ("m_xcd18", dict(xcd=5)),
-    # session N: deferred running maximum in the pipelined attention key loop (attn = 3, the default) vs the textbook rule (2)
-    ("n_attn2", dict(attn=2)),
-    ("n_attn3", dict(attn=3)),
-    ("k_s4", dict()),
-    ("k_s4_geglu64_128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1]})),
-    ("k_s4_geglu_both128", dict(tuning={"32768,5120,640,0,1": [128, 128, 1], "8192,10240,1280,0,1": [128, 128, 1]})),
+    # round 4 (the round-2 / round-3 sessions' configurations are in git history; their results in profiles/r03_forward_ab_*.json)
+    ("base", dict()),
+    # self-attention key loop (imh_debug_set key 4): 1 in-order, 3 software-pipelined + deferred maximum (the round-3 default),
+    # 5 key-split workgroups (round 4)
+    ("attn1", dict(attn=1)),
+    ("attn3", dict(attn=3)),
+    ("attn5", dict(attn=5)),
+    # LayerNorm statistics from stand-alone row-statistics launches instead of the producers' epilogues
+    ("ln_rowstats", dict(ln_stats=False)),
+    ("gn_off", dict(gn_stats=False)),
+    # GroupNorm + SiLU + concat inside the LDS-halo convs (round 4) vs table + apply passes + materialised concats
+    ("gn_unfused", dict(gn_fuse=False)),
+    ("gn_fused", dict(gn_fuse=True)),
+    ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)),
 ])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--configs", default="j_gn_off,j_gn_on")
+    ap.add_argument("--configs", default="base")
     ap.add_argument("--stacked", type=int, default=1)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
@@ -96,8 +60,8 @@ def main():
     for n in names:
         c = CONFIGS[n]
         U.LN_STATS_HANDOVER = bool(c.get("ln_stats", True))
-        U.XATTN_STATS_HANDOVER = bool(c.get("xstats", False))
         U.GN_STATS_HANDOVER = bool(c.get("gn_stats", True))
+        U.GN_FUSE = bool(c.get("gn_fuse", True))
         AP.DUAL_WS = bool(c.get("dual_ws", False))
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
