@@ -30,6 +30,10 @@ HEAD_DIM = 64
 # launch in the forward against 36.9 for the two-stage 128-row tiles (profiles/r03_forward_ab_dualws.json) -- its 416 workgroups
 # run as two rounds of one workgroup per CU, and both forms are bound by the same L2 -> LDS rate
 DUAL_WS = os.environ.get("IMH_DUAL_WS", "0") != "0"
+# [Q|K|V] of a self-attention layer as ONE wave-specialised launch (imh_gemm_args.Yt: the V third leaves the kernel transposed);
+# widths it is used for (A/B: IMH_QKV_ONE=0 keeps the two-problem launch; IMH_QKV_ONE_WIDTHS=1280 restricts it)
+QKV_ONE = os.environ.get("IMH_QKV_ONE", "1") != "0"
+QKV_ONE_WIDTHS = tuple(int(v) for v in os.environ.get("IMH_QKV_ONE_WIDTHS", "640,1280").split(",") if v)
 
 
 def _pad64(n):
@@ -142,7 +146,7 @@ class AttnProcessor2_0(nn.Module):
         """x: [B*L, C].  Returns to_out(attention(x)) (+ residual).
         ln = norm module: x is the UN-normalised residual stream and that LayerNorm is folded into the projections;
         ln_stats = (tensor, slots): the rows' statistics as left by the GEMM that wrote x (csrc/imh_lnstats.h), None -> taken
-        inside the projection GEMMs' K loops.  Without ln, x is already layer-normed.
+        supplied by a row-statistics launch (Ctx.gemm_dual).  Without ln, x is already layer-normed.
         want_stats: also return the row statistics of the result (the next LayerNorm's input) -> (out, stats).
         lk < L_: only the first lk rows of every batch are real keys (zero-padded sequence)."""
         C_ = x.shape[1]
@@ -160,10 +164,19 @@ class AttnProcessor2_0(nn.Module):
                 fold_ln(attn.to_v.weight, norm, ctx)))
             g1 = dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], norm.eps, ln_stats))
             g2 = dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], norm.eps, ln_stats))
-        # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch -- with handed-over LayerNorm statistics
-        # the wave-specialised pair (variant 24128: 128 x 160 + 128 x 128 tiles), else the two-stage 128-row tiles
-        ws = ln is not None and ln_stats is not None and DUAL_WS and (B * L_) % 128 == 0 and C_ % 160 == 0
-        qk, vt = ctx.gemm_dual(g1, g2, cfg=(24128, 160) if ws else (128, 64), descr="self.to_qk+v^T")
+        if ln is not None and ln_stats is not None and QKV_ONE and (B * L_) % 256 == 0 and C_ % 160 == 0 and C_ in QKV_ONE_WIDTHS:
+            # [Q|K|V] = LN(x) [Wq;Wk;Wv]^T as ONE wave-specialised launch of 256 x 160 tiles (M = 2048, N = 3840: 192 tiles, one
+            # round); the V third leaves the kernel transposed through LDS, in the V^T layout the attention's PV operand reads
+            f3 = _cached(attn, "_imh_ln_qkv3", key, lambda: fold_ln(
+                torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach(), attn.to_v.weight.detach()], 0), norm, ctx))
+            vt = ctx.new(C_, B * L_)
+            qk = ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], norm.eps, ln_stats), cfg=(23256, 160, 1), yt=(vt, 2 * C_),
+                          descr="self.to_qkv")
+        else:
+            # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch -- with handed-over LayerNorm statistics
+            # the wave-specialised pair (variant 24128: 128 x 160 + 128 x 128 tiles), else the two-stage 128-row tiles
+            ws = ln is not None and ln_stats is not None and DUAL_WS and (B * L_) % 128 == 0 and C_ % 160 == 0
+            qk, vt = ctx.gemm_dual(g1, g2, cfg=(24128, 160) if ws else (128, 64), descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,
                       HEAD_DIM ** -0.5, descr="self.attn")

@@ -37,6 +37,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.ln_stats = a->ln_stats; p.ln_stats_out = a->ln_stats_out; p.ln_slots = a->ln_slots; p.ln_slots_out = a->ln_slots_out;
     p.gn_out = a->gn_out; p.gn_nblk = a->gn_nblk; p.gn_hw = a->gn_hw;
     p.gn_tab = a->gn_tab; p.gn_silu = a->gn_silu; p.X2 = a->X2; p.Cin1 = a->X2 ? a->Cin1 : a->Cin;
+    p.Yt = a->Yt; p.yt_col0 = a->yt_col0; p.ldyt = a->ldyt;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;

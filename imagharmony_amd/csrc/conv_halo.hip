@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
     const float* const gtab = (const float*)(smem + 2 * CH_HALO_BYTES + S * CH_W_BYTES);     // [Cin][2] (scale, shift) of this sample (p.gn_tab)
     static_assert(S >= 2 && (S - 2) * WQ + HQ <= 15, "vmcnt switch range");
+    static_assert(S + HQ <= 9, "the next chunk's halo is normalised piece by piece inside the current chunk's nine taps");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     // GroupNorm (+ SiLU) of the staged chunk, in place, by the wave that staged it (its own DMA pieces: its own vmcnt wait covers them);
     // every piece of a lane holds the same logical 16-B chunk (h & 7 == (lane >> 3) & 7 whatever the piece), i.e. the same 8 channels
     const int gch = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-    auto norm_halo = [&](int buf, int ct) {
+    // pieces [q0, q1) of the wave (one piece = 8 halo pixels x 64 channels; ~70 VALU instructions per lane)
+    auto norm_halo = [&](int buf, int ct, int q0, int q1) {
         unsigned char* d = halo0 + buf * CH_HALO_BYTES;
         float sc[8], sh[8];
         const f32x4* tb = (const f32x4*)(gtab + (ct * GEMM_BK + gch) * 2);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
         for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
-            if (q * 8 + wave < HPIECES) {
+            if (q >= q0 && q < q1 && q * 8 + wave < HPIECES) {
                 v8* a = (v8*)(d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES + lane * 16);
                 const v8 t = *a;
                 v8 o;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
         if (j < nsteps) stage_w(j % S, step_ct(j), j - 9 * step_ct(j));
     if (gn) {                                           // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
         wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
-        norm_halo(0, 0);
+        norm_halo(0, 0, 0, HQ);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written back before the barrier of step 0 publishes the halo
     }
     int step = 0;
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
             if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
             // ... and normalised in place once it has landed for this wave: the wait above stops counting it from tap S on (it is older
             // than every weight step still in flight); the barrier of the next chunk's tap 0 publishes the result
-            if (gn && tap == S && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1);
+            // -- one piece per tap (taps S .. S + HQ - 1 <= 8), so that no step carries more than ~70 extra VALU instructions beside its
+            // 40 MFMAs per wave
+            if (gn && tap >= S && tap < S + HQ && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1, tap - S, tap - S + 1);
             const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES;
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
 #pragma unroll

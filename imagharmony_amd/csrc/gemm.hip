@@ -501,6 +501,16 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
             }
         }
         if (!p.X2) p.Cin1 = conv ? p.Cin : p.K;
+        if (p.Yt) {      // transposed V^T store of the columns >= yt_col0: the lean LN epilogue of the wave-specialised kernels
+            const int rows = bm == 23256 ? 256 : (bm == 24128 || bm == 22128 ? 128 : 64);
+            if (!ws || bn != 160 || conv || p.flags != GF_LN_ROW || p.residual || p.rowadd || p.splits > 1 || p.M % rows || p.N % 160 ||
+                p.yt_col0 <= 0 || p.yt_col0 >= p.N || p.yt_col0 % 160 || (p.ldyt & 7) || p.ldyt < p.M || (p.ldy & 7)) {
+                set_error("gemm: Yt (transposed V^T store) needs a wave-specialised bn = 160 variant, flags == IMH_GF_LN_ROW only, no residual / "
+                          "row-add / split-K, whole tiles (M %% %d, N %% 160), 0 < yt_col0 < N a multiple of 160, ldyt >= M a multiple of 8 "
+                          "(bm=%d M=%d N=%d yt_col0=%d ldyt=%d flags=%d)", rows, bm, p.M, p.N, p.yt_col0, p.ldyt, p.flags);
+                return IMH_ERR_ARG;
+            }
+        }
     }
     if (dtype == IMH_DT_BF16) return launch_typed<bf16_t>(p, conv, bm, bn, stream);
     if (dtype == IMH_DT_F16) return launch_typed<f16_t>(p, conv, bm, bn, stream);

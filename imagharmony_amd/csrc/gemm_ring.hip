@@ -662,6 +662,39 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
 #pragma unroll
                 for (int q = 0; q < NV; ++q) pre.bias[q] = 0.f;
             }
+            if (p.Yt && n0 >= p.yt_col0) {
+                // TRANSPOSED store (the V third of the self-attention's [Q|K|V] launch): column n of this tile becomes row
+                // n - yt_col0 of Yt [., ldyt], token m its column, the 16 tokens of every fragment row group stored in the order
+                // [0-3, 8-11, 4-7, 12-15] (imh_layout.h vt_perm16: the V^T layout the attention kernels' PV operand reads with one
+                // ds_read_b128).  Through the wave's own slab of the dead ring: [TN channels][TM tokens], written as 2-byte values
+                // (lane = token, 20 / 40 channels), read back as whole TM-token rows and stored coalesced.  The launcher guarantees
+                // whole tiles (M % BM == 0, N % BN == 0) and yt_col0 % BN == 0.
+                T* stg = (T*)(smem + wave * (TM * TN * (int)sizeof(T)));
+                const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int pos = i * 16 + vt_perm16(r);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int q = j * 4 + rr;
+                            const float y = fma_nopk(st_q[i], fma_nopk(-st_s[i], lnpre[q], acc[i][j][rr]), lnpre[NV + q]) + pre.bias[q];
+                            stg[(g * NV + q) * TM + pos] = from_f32<T>(y);
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS hand-off (DS operations retire in order)
+                constexpr int LPR = TM / 8;                              // lanes per transposed row (16 B each)
+                constexpr int RPP = 64 / LPR;                            // rows per pass
+                T* yt = (T*)p.Yt + (size_t)(n0 - p.yt_col0 + wn * TN) * p.ldyt + (m0 + wm * TM);
+#pragma unroll
+                for (int ps = 0; ps < TN / RPP; ++ps) {
+                    const int row = ps * RPP + lane / LPR, ch = lane % LPR;
+                    const v8 t8 = *(const v8*)(stg + row * TM + ch * 8);
+                    *(v8*)(yt + (size_t)row * p.ldyt + ch * 8) = t8;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + (lane & 15);

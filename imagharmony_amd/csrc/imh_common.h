@@ -95,7 +95,11 @@ __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) as 1 mul + v_exp + add + v_rcp + mul (an IEEE divide here costs ~10 more instructions; the result is rounded to
+// bf16 / fp16 anyway); exp2 overflow for x << 0 gives rcp(inf) = 0 -> -0, the limit
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 // exact-erf GELU (diffusers GEGLU / nn.GELU()) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far
 // below bf16/fp16 output resolution): 1 rcp + 1 exp + 7 fma instead of libm erff's ~40 instructions.
 __device__ __forceinline__ float erf_as(float x) {

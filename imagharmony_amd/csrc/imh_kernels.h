@@ -34,6 +34,10 @@ struct GemmParams {
     // channel concat as the conv input: channels [0, Cin1) come from X (pixel stride Cin1), [Cin1, Cin) from X2 (pixel stride Cin - Cin1)
     const void* X2;
     int Cin1;
+    // wave-specialised row-form folded-LayerNorm launches: output columns >= yt_col0 are stored TRANSPOSED (V^T layout, 16-token
+    // groups permuted) into Yt [N - yt_col0, ldyt] instead of Y -- the V third of the self-attention's one-launch [Q|K|V]
+    void* Yt;
+    int yt_col0, ldyt;
     int M, N, K;
     int ldx, ldw, ldy, ldr, ldra;
     int rows_per_batch;

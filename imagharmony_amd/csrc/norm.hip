@@ -108,66 +108,74 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p
     }
 }
 
-// step 2: one workgroup per sample.  16 slices x 32 group lanes add up, in double, S = sum_i sum_i, Q = sum_i (M2_i + sum_i^2 / n_i),
-// N = sum_i n_i over the partials of their group (fixed order), then mean = S / N, var = (Q - S^2 / N) / N -- the between-partial term
-// in double, the within-partial terms already centred.  Source 1 covers channels [0, C1), source 2 (optional) [C1, C).
-// npart > 0: elements per partial (a producer epilogue: block rows x sub); npart == 0: the ragged blocks of gn_stats_kernel
-// ((pixels of block k) * sub with ppb = ceil(HW / nblk)).
-__global__ __launch_bounds__(GN_THREADS) void gn_table_kernel(const NormParams p) {
-    __shared__ double part_s[16][64], part_q[16][64], part_n[16][64];
-    __shared__ float mean_s[64], rstd_s[64];
-    const int b = blockIdx.x, t = threadIdx.x;
+// step 2: one workgroup per (sample, group): its 256 threads stride over the group's partials -- (pixel block, sub-run) pairs of
+// one or two sources -- with one load each per round, adding up in double S = sum_i sum_i, Q = sum_i (M2_i + sum_i^2 / n_i),
+// N = sum_i n_i; a fixed-order reduction (lanes by butterfly, waves through LDS: deterministic) gives mean = S / N,
+// var = (Q - S^2 / N) / N -- the between-partial term in double, the within-partial terms already centred -- and the group's cpg
+// threads write (scale, shift).  Source 1 covers channels [0, C1), source 2 (optional) [C1, C).  npart > 0: elements per partial (a
+// producer epilogue: block rows x sub); npart == 0: the ragged blocks of gn_stats_kernel ((pixels of block k) * sub, ppb = ceil(HW /
+// nblk)).  (The first version ran one workgroup per SAMPLE with a serial walk per group: 10-16 us per launch, 46 launches per
+// forward -- profiles/r04_forward_ab_gn.json.)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void gn_table_kernel(const NormParams p) {
+    __shared__ double red[3][4];
+    __shared__ float ms[2];
+    const int gg = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const int C = p.C, cpg = C / p.groups;
     typedef __attribute__((ext_vector_type(2))) float f2;
-    {
-        const int g = t % 32, sl = t / 32;
-        for (int gg = g; gg < p.groups; gg += 32) {
-            double S = 0.0, Q = 0.0, N = 0.0;
-            const int c0 = gg * cpg, c1 = c0 + cpg;
+    double S = 0.0, Q = 0.0, N = 0.0;
+    const int c0 = gg * cpg, c1 = c0 + cpg;
 #pragma unroll 1
-            for (int src = 0; src < 2; ++src) {
-                const float* pp = src == 0 ? p.partial : p.partial2;
-                if (!pp) continue;
-                const int cb = src == 0 ? 0 : p.C1, ce = src == 0 ? p.C1 : C;          // channel range of this source
-                const int lo = max(c0, cb), hi = min(c1, ce);
-                if (lo >= hi) continue;
-                const int sub = src == 0 ? p.sub : p.sub2, nblk = src == 0 ? p.nblk : p.nblk2, npart = src == 0 ? p.npart : p.npart2;
-                const int nsub = (ce - cb) / sub;
-                const int j0 = (lo - cb) / sub, j1 = (hi - cb) / sub;
-                const int ppb = (p.HW + nblk - 1) / nblk;
-                const f2* base = (const f2*)pp + (size_t)b * nblk * nsub;
-                for (int k = sl; k < nblk; k += 16) {
-                    const double n = npart > 0 ? (double)npart : (double)(min(p.HW, (k + 1) * ppb) - k * ppb) * sub;
-                    if (n <= 0.0) continue;
-                    for (int j = j0; j < j1; ++j) {
-                        const f2 v = base[(size_t)k * nsub + j];
-                        S += (double)v[0];
-                        Q += (double)v[1] + (double)v[0] * (double)v[0] / n;
-                        N += n;
-                    }
-                }
+    for (int src = 0; src < 2; ++src) {
+        const float* pp = src == 0 ? p.partial : p.partial2;
+        if (!pp) continue;
+        const int cb = src == 0 ? 0 : p.C1, ce = src == 0 ? p.C1 : C;          // channel range of this source
+        const int lo = max(c0, cb), hi = min(c1, ce);
+        if (lo >= hi) continue;
+        const int sub = src == 0 ? p.sub : p.sub2, nblk = src == 0 ? p.nblk : p.nblk2, npart = src == 0 ? p.npart : p.npart2;
+        const int nsub = (ce - cb) / sub;
+        const int j0 = (lo - cb) / sub, nj = (hi - cb) / sub - j0;
+        const int ppb = (p.HW + nblk - 1) / nblk;
+        const f2* base = (const f2*)pp + (size_t)b * nblk * nsub + j0;
+        const int total = nblk * nj;
+        const double inv_const = npart > 0 ? 1.0 / (double)npart : 0.0;
+        for (int e = t; e < total; e += 256) {
+            const int k = e / nj, j = e - k * nj;
+            const f2 v = base[(size_t)k * nsub + j];
+            double n, inv;
+            if (npart > 0) { n = (double)npart; inv = inv_const; }
+            else { n = (double)(min(p.HW, (k + 1) * ppb) - k * ppb) * sub; inv = n > 0.0 ? 1.0 / n : 0.0; }
+            if (n > 0.0) {
+                S += (double)v[0];
+                Q += (double)v[1] + (double)v[0] * (double)v[0] * inv;
+                N += n;
             }
-            part_s[sl][gg] = S; part_q[sl][gg] = Q; part_n[sl][gg] = N;
         }
     }
+    S = wave_sum_d(S); Q = wave_sum_d(Q); N = wave_sum_d(N);
+    if ((t & 63) == 0) { red[0][t >> 6] = S; red[1][t >> 6] = Q; red[2][t >> 6] = N; }
     __syncthreads();
-    if (t < p.groups) {
-        double S = 0.0, Q = 0.0, N = 0.0;
-        for (int sl = 0; sl < 16; ++sl) { S += part_s[sl][t]; Q += part_q[sl][t]; N += part_n[sl][t]; }
-        const double mean = S / N;
-        double var = (Q - S * S / N) / N;
+    if (t == 0) {
+        const double S4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double Q4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double N4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        const double mean = S4 / N4;
+        double var = (Q4 - S4 * S4 / N4) / N4;
         if (var < 0.0) var = 0.0;
-        mean_s[t] = (float)mean;
-        rstd_s[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+        ms[0] = (float)mean;
+        ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     __syncthreads();
     float* tab = p.table + (size_t)b * C * 2;
-    for (int c = t; c < C; c += GN_THREADS) {
-        const int g = c / cpg;
+    for (int c = c0 + t; c < c1; c += 256) {
         const float gm = p.gamma ? (p.dtype_f16 ? to_f32(((const f16_t*)p.gamma)[c]) : to_f32(((const bf16_t*)p.gamma)[c])) : 1.f;
         const float bt = p.beta ? (p.dtype_f16 ? to_f32(((const f16_t*)p.beta)[c]) : to_f32(((const bf16_t*)p.beta)[c])) : 0.f;
-        const float sc = gm * rstd_s[g];
-        f2 o = {sc, bt - mean_s[g] * sc};
+        const float sc = gm * ms[1];
+        f2 o = {sc, bt - ms[0] * sc};
         *(f2*)(tab + (size_t)c * 2) = o;
     }
 }
@@ -251,7 +259,7 @@ int groupnorm_launch(const NormParams& p0, int dtype, hipStream_t stream) {
             set_error("groupnorm table: sub-runs must tile the groups (C=%d groups=%d C1=%d sub=%d/%d nblk=%d/%d) and eps > 0", p.C, p.groups, p.C1, p.sub, p.sub2, p.nblk, p.nblk2);
             return IMH_ERR_ARG;
         }
-        hipLaunchKernelGGL(gn_table_kernel, dim3(p.B), dim3(GN_THREADS), 0, stream, p);
+        hipLaunchKernelGGL(gn_table_kernel, dim3(p.groups, p.B), dim3(256), 0, stream, p);
         if (mode == 2) return check_launch("gn_table_kernel");
     }
     if (!p.x || !p.y || !p.table) { set_error("groupnorm: apply needs x, y and a table"); return IMH_ERR_ARG; }

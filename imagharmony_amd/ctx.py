@@ -203,7 +203,7 @@ class Ctx:
 
     def gemm(self, x, w, out=None, bias=None, residual=None, rowadd=None, rows_per_batch=0, ldra=0, flags=0,
              M=None, N=None, K=None, ldx=None, ldw=None, ldy=None, ldr=None, cfg=None, descr="gemm", out_dtype=None,
-             ln=None, stats_out=False, gn_out=None, x2=None, _args_only=False):
+             ln=None, stats_out=False, gn_out=None, x2=None, yt=None, _args_only=False):
         """y[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x / w: 2-D, last dim contiguous.
         ln = (s, c, eps[, stats]) with GF_LN_ROW / GF_LN_COL in flags: LayerNorm of the token operand folded into the GEMM
         (w pre-scaled by gamma); stats = (tensor [tokens, slots, 2] fp32, slots) are the token rows' statistics as handed
@@ -214,6 +214,8 @@ class Ctx:
         gn_out=hw (rows per sample; a (groups, hw) pair is accepted, the groups are the consumer's business): y is a GroupNorm
         input -> (y, gn) with gn = GnStats from the epilogue, or None when the chosen variant has no such epilogue (the consumer
         then runs gn_stats over y).
+        yt = (Yt [N - col0, ldyt], col0): output columns >= col0 are stored transposed in the V^T layout into Yt instead of y (y
+        then holds columns [0, col0)); wave-specialised bn = 160 variants, flags == GF_LN_ROW only (the one-launch [Q|K|V]).
         x2: the token operand is the column concat [x | x2] (K = x.shape[1] + x2.shape[1]; the up blocks' conv_shortcut over
         torch.cat([hidden, skip], 1)) read from its two producers -- plain 64 / 128 tiles and the wave-specialised variants."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
@@ -230,6 +232,8 @@ class Ctx:
         if isinstance(gn_out, tuple):
             gn_out = gn_out[1]
         n_out = N // 2 if flags & L.GF_GEGLU else N
+        if yt is not None:
+            n_out = int(yt[1])
         if out is None:
             out = self.new(M, n_out, dtype=torch.float32 if flags & L.GF_OUT_F32 else None)
         ln_stats = ln[3] if ln is not None and len(ln) > 3 else None
@@ -255,6 +259,11 @@ class Ctx:
         a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
         if x2 is not None:
             a.X2, a.Cin1 = x2.data_ptr(), x.shape[1]
+        if yt is not None:
+            self._chk(yt[0], descr + ".yt")
+            if yt[0].dim() != 2 or yt[0].stride(1) != 1 or yt[0].shape[0] != N - int(yt[1]) or yt[0].shape[1] < M:
+                raise L.ImhError(f"{descr}: yt {tuple(yt[0].shape)} does not fit [{N - int(yt[1])}, >= {M}]")
+            a.Yt, a.yt_col0, a.ldyt = yt[0].data_ptr(), int(yt[1]), yt[0].stride(0)
         a.bias, a.rowadd, a.residual = self._p(bias), self._p(rowadd), self._p(residual)
         keep_ln = ()
         if ln is not None:           # (s, c fp32, eps[, stats]); the caller sets GF_LN_ROW / GF_LN_COL in flags
@@ -284,12 +293,14 @@ class Ctx:
         if _args_only:
             return a, out, 2.0 * M * N * K, es * (M * K + N * K + M * n_out), (x, w, out, bias, rowadd, residual, x2) + keep_ln
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K, nbytes=es * (M * K + N * K + M * n_out),
-                   keep=(x, w, out, bias, rowadd, residual, x2) + keep_ln + ((st[0],) if st else ()) + ((gn.t,) if gn else ()),
+                   keep=(x, w, out, bias, rowadd, residual, x2) + keep_ln + ((st[0],) if st else ()) + ((gn.t,) if gn else ())
+                   + ((yt[0],) if yt is not None else ()),
                    shape=(M, N, K, 0, None),
                    epi=dict(flags=flags, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
                             rows_per_batch=rows_per_batch, cfg=(bm, bn, sp), ln_pre=ln_stats is not None,
                             ln_slots=int(ln_stats[1]) if ln_stats is not None else 0, stats_out=st is not None,
-                            gn_out=(gn.nblk, gn_out) if gn else None, x2=x.shape[1] if x2 is not None else 0))
+                            gn_out=(gn.nblk, gn_out) if gn else None, x2=x.shape[1] if x2 is not None else 0,
+                            yt=int(yt[1]) if yt is not None else 0))
         if own_stats:
             self.free(ln_stats[0])
         if stats_out:

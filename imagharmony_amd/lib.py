@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
                 ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
                 ("ln_stats", _vp), ("ln_stats_out", _vp), ("ln_slots", _i32), ("ln_slots_out", _i32),
-                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_hw", _i32), ("gn_tab", _vp), ("gn_silu", _i32), ("X2", _vp), ("Cin1", _i32),
+                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_hw", _i32), ("gn_tab", _vp), ("gn_silu", _i32), ("X2", _vp), ("Cin1", _i32), ("Yt", _vp), ("yt_col0", _i32), ("ldyt", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),

@@ -123,6 +123,13 @@ typedef struct imh_gemm_args {
      * multiples of 64.  X2 == NULL -> one source. */
     const void* X2;
     int32_t Cin1;
+    /* Wave-specialised variants at bn = 160 with flags == IMH_GF_LN_ROW (the self-attention projections, attention_processor.py:
+     * 292-300, as ONE launch over W = [Wq; Wk; Wv]): output columns n >= yt_col0 are not written to Y but TRANSPOSED to
+     * Yt[(n - yt_col0) * ldyt + m'] with the 16 tokens of every aligned group stored as [0-3, 8-11, 4-7, 12-15] -- the V^T operand
+     * layout of imh_attention (what IMH_GF_VT_PERM produces for the swapped-operand form).  Whole tiles only (M a multiple of the
+     * variant's rows, N and yt_col0 multiples of 160); Y receives columns [0, yt_col0) with row stride ldy.  NULL -> all of Y. */
+    void* Yt;
+    int32_t yt_col0, ldyt;
     int32_t M, N, K;
     int32_t ldx, ldw, ldy, ldr, ldra;   /* ldra: row stride of rowadd (0 -> N) */
     int32_t rows_per_batch;

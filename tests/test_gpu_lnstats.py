@@ -191,3 +191,42 @@ def test_wave_specialised_projection_pair(L, dtype):
     qk3, vt3 = ctx.gemm_dual(dict(x=x, w=fq[0], flags=L.GF_LN_ROW, ln=(fq[1], fq[2], 1e-5)),
                              dict(x=fv[0], w=x, flags=L.GF_VT_PERM | L.GF_LN_COL, ln=(fv[1], fv[2], 1e-5)), cfg=(24128, 160))
     assert torch.equal(qk3, qk) and torch.equal(vt3, vt)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(23256, 160, 1), (24128, 160, 1), (2464, 160, 1), (1464, 160, 1)])
+def test_one_launch_qkv_with_transposed_v(L, dtype, cfg):
+    """[Q|K|V] = LN(x) [Wq;Wk;Wv]^T as ONE wave-specialised launch (imh_gemm_args.Yt): Q and K land row-major in y [M, 2C], the V
+    columns leave the kernel transposed through LDS in the V^T layout (16-token groups permuted) -- equal, bit for bit, to what
+    the two-problem launch of round 3 produces with the same statistics, and to torch within rounding; feeds imh_attention as is
+    (reference: attention_processor.py:292-316)"""
+    from imagharmony_amd.attention_processor import fold_ln
+    from test_gpu_ops import make_vt, sdpa_ref
+    ctx = ctx_for(dtype)
+    for (B, Lq, C_) in [(2, 256, 320), (2, 1024, 1280), (1, 512, 640)]:
+        M = B * Lq
+        x = (rnd(M, C_, dtype=dtype, seed=1) * 1.5 + 2.0).contiguous()
+        w3 = rnd(3 * C_, C_, dtype=torch.float32, seed=2, scale=C_ ** -0.5)
+        norm = _norm(C_)
+        xn = F.layer_norm(x.float().cpu(), (C_,), norm.weight, norm.bias, 1e-5)
+        f3 = fold_ln(w3, norm, ctx)
+        st = _stats_for(ctx, x, 80)
+        vt = torch.zeros(C_, M, dtype=dtype, device=DEV)
+        qk = ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], 1e-5, st), cfg=cfg, yt=(vt, 2 * C_))
+        assert tuple(qk.shape) == (M, 2 * C_)
+        ref = (xn @ w3.cpu().t()).to(DEV)
+        assert_close(qk, ref[:, :2 * C_], dtype, f"[Q|K] {cfg} {(B, Lq, C_)}", k=6.0)
+        assert_close(vt_unpermute(vt), ref[:, 2 * C_:].t(), dtype, f"V^T {cfg} {(B, Lq, C_)}", k=6.0)
+        # the same numbers as the plain row-form launch over all 3C columns, transposed + permuted by torch
+        full = ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], 1e-5, st), cfg=cfg)
+        assert torch.equal(full[:, :2 * C_], qk)
+        v = full[:, 2 * C_:].reshape(B, Lq, C_)
+        assert torch.equal(make_vt(v, Lq), vt), "transposed epilogue == torch transpose + 16-group permutation of the plain store"
+        vt2 = torch.zeros_like(vt)
+        assert torch.equal(ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], 1e-5, st), cfg=cfg, yt=(vt2, 2 * C_)), qk) and torch.equal(vt2, vt)
+        H = C_ // 64
+        out = ctx.new(M, C_)
+        ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, M, C_, 0.125)
+        assert_close(out.view(B, Lq, C_), sdpa_ref(qk[:, :C_].reshape(B, Lq, C_), qk[:, C_:].reshape(B, Lq, C_), v, H), dtype, "attention on the one-launch projections", k=6.0)
+    with pytest.raises(L.ImhError, match="Yt"):
+        ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], 1e-5, st), cfg=(128, 128, 1), yt=(vt, 2 * C_))

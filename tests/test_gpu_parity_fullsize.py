@@ -381,10 +381,17 @@ def test_every_gemm_and_conv_variant_of_the_benchmarked_forward(dtype):
                 norm = _rand_norm(K)
                 wg, s_, c_ = fold_ln(w.float(), norm, ctx)
                 st = (ref_row_stats(x.float(), epi["ln_slots"]).to(DEV), epi["ln_slots"]) if epi.get("ln_pre") else None
+                yt = (torch.zeros(N - epi["yt"], M, dtype=dtype, device=DEV), epi["yt"]) if epi.get("yt") else None
                 y = ctx.gemm(x, wg, bias=bias, residual=residual, rowadd=rowadd, rows_per_batch=rpb if rowadd is not None else 0,
-                             flags=epi["flags"], ln=(s_, c_, 1e-5, st), cfg=(bm, bn, sp), descr=descr)
+                             flags=epi["flags"], ln=(s_, c_, 1e-5, st), cfg=(bm, bn, sp), descr=descr, yt=yt)
                 xn = F.layer_norm(x.float(), (K,), norm.weight.to(DEV), norm.bias.to(DEV), 1e-5)
-                _close(y, _ref_epilogue(xn @ w.float().t(), epi, bias, residual, rowadd, L), dtype, f"{descr} {shape} {epi}", k=6.0)
+                full = _ref_epilogue(xn @ w.float().t(), epi, bias, residual, rowadd, L)
+                if yt is not None:        # the one-launch [Q|K|V]: the V columns left the kernel transposed, 16-token groups permuted
+                    _close(y, full[:, :epi["yt"]], dtype, f"{descr} {shape} {epi} [Q|K]", k=6.0)
+                    vt = yt[0].float().view(N - epi["yt"], M // 16, 4, 4)[:, :, [0, 2, 1, 3], :].reshape(N - epi["yt"], M)
+                    _close(vt, full[:, epi["yt"]:].t(), dtype, f"{descr} {shape} {epi} V^T", k=6.0)
+                else:
+                    _close(y, full, dtype, f"{descr} {shape} {epi}", k=6.0)
             else:
                 assert not epi["flags"] & L.GF_LN_COL
                 xa, x2 = (x[:, :epi["x2"]].contiguous(), x[:, epi["x2"]:].contiguous()) if epi.get("x2") else (x, None)

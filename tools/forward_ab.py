@@ -40,6 +40,10 @@ CONFIGS = collections.OrderedDict([
     # GroupNorm + SiLU + concat inside the LDS-halo convs (round 4) vs table + apply passes + materialised concats
     ("gn_unfused", dict(gn_fuse=False)),
     ("gn_fused", dict(gn_fuse=True)),
+    # self-attention projections: the two-problem launch of round 3 vs ONE wave-specialised [Q|K|V] launch (at both widths / at C = 1280 only)
+    ("qkv_dual", dict(qkv_one=False)),
+    ("qkv_one", dict(qkv_one=True)),
+    ("qkv_one_1280", dict(qkv_one=True, qkv_widths=(1280,))),
     ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)),
 ])
 
@@ -63,6 +67,8 @@ def main():
         U.GN_STATS_HANDOVER = bool(c.get("gn_stats", True))
         U.GN_FUSE = bool(c.get("gn_fuse", True))
         AP.DUAL_WS = bool(c.get("dual_ws", False))
+        AP.QKV_ONE = bool(c.get("qkv_one", True))
+        AP.QKV_ONE_WIDTHS = tuple(c.get("qkv_widths", (640, 1280)))
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
         lib.imh_debug_set(2, int(c.get("xcd", 0)))
