@@ -226,6 +226,7 @@ int imh_debug_set(int key, int value) {
     if (key == 2) { g_xcd_mode = value; return IMH_OK; }
     if (key == 3) { g_xattn_mode = value; return IMH_OK; }
     if (key == 4) { g_attn_mode = value; return IMH_OK; }
+    if (key == 5) { g_halo_mode = value; return IMH_OK; }
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;
 }

@@ -31,6 +31,8 @@
 
 namespace imh {
 
+int g_halo_mode = 0;
+
 constexpr int CH_PW = 16;                                 // output patch width (one MFMA token fragment)
 constexpr int CH_HW = CH_PW + 2;                          // halo row length (18)
 // FN = weight fragments per wave: 10 -> 320 couts per workgroup (one tile per CU at the 128^2 latent with 320 channels),
@@ -62,12 +64,19 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
     }
 }
 
-template <typename T, int FN, int FM, int S>
-__global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
+// HWV = 0: eight waves do everything (rounds 2-3).  HWV = 4 (round 4): four extra HALO waves own the input side -- they issue the
+// halo LDS-DMA of the next chunk and normalise it in place (GroupNorm + SiLU, p.gn_tab), two pieces per tap, while the eight MFMA
+// waves only stream weights, read fragments and issue MFMAs: the ~280 VALU-issue cycles per staged piece (41 pieces per chunk at the
+// 16 x 16 patch) no longer stall a wave that feeds the matrix pipe (with all of it inside the MFMA waves the fused launch ran
+// 13-21 us longer than the plain conv -- exactly what the stand-alone apply pass costs; profiles/r04_forward_ab_qkv_gn.json).
+// One s_barrier per (chunk, tap) step carries every hand-over, as before.
+template <typename T, int FN, int FM, int S, int HWV>
+__global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
+    constexpr int NSTG = HWV ? HWV : 8;                     // waves that stage the halo
     constexpr int CH_PH = 4 * FM;                           // output patch height
     constexpr int CH_HALO = (CH_PH + 2) * CH_HW;            // 180 / 108 halo pixels
     constexpr int HPIECES = (CH_HALO + 7) / 8;              // 23 / 14 staging pieces of 8 halo pixels
-    constexpr int HQ = (HPIECES + 7) / 8;                   // ... per wave
+    constexpr int HQ = (HPIECES + NSTG - 1) / NSTG;         // ... per staging wave
     constexpr int CH_HALO_BYTES = HPIECES * 8 * GEMM_ROW_BYTES;
     constexpr int CH_BN = 32 * FN;
     constexpr int CH_W_BYTES = CH_BN * GEMM_ROW_BYTES;
@@ -78,13 +87,15 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     unsigned char* halo0 = smem;
     unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
     const float* const gtab = (const float*)(smem + 2 * CH_HALO_BYTES + S * CH_W_BYTES);     // [Cin][2] (scale, shift) of this sample (p.gn_tab)
-    static_assert(S >= 2 && (S - 2) * WQ + HQ <= 15, "vmcnt switch range");
-    static_assert(S + HQ <= 9, "the next chunk's halo is normalised piece by piece inside the current chunk's nine taps");
+    static_assert(S >= 2 && (S - 2) * WQ + (HWV ? 0 : HQ) <= 15, "vmcnt switch range");
+    static_assert(HWV ? (HQ <= 14) : (S + HQ <= 9), "the next chunk's halo is normalised piece by piece inside the current chunk's nine taps");
+    constexpr int NT = 64 * (8 + HWV);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave & 7) >> 1, wn = wave & 1;
+    const int sw = HWV ? wave - 8 : wave;                  // index among the halo-staging waves (negative: an MFMA wave of the HWV form)
 
     // tile coordinates: cout tile fastest, then patch column, row, batch
     int t = blockIdx.x;
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     int hstep[HQ];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
-        const int piece = q * 8 + wave;
+        const int piece = q * NSTG + (sw < 0 ? 0 : sw);
         const int h = piece * 8 + (lane >> 3);              // halo pixel index (may run past the halo on the last piece)
         const int hy = h / CH_HW, hx = h - hy * CH_HW;
         const int iy = ty * CH_PH + hy - 1, ix = tx * CH_PW + hx - 1;
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
         const int cc = second ? ct - cpt1 : ct;
 #pragma unroll
         for (int q = 0; q < HQ; ++q)
-            if (q * 8 + wave < HPIECES) glds16((second ? hsrc2[q] : hsrc[q]) + (size_t)cc * hstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+            if (q * NSTG + sw < HPIECES) glds16((second ? hsrc2[q] : hsrc[q]) + (size_t)cc * hstep[q], d + (q * NSTG + sw) * 8 * GEMM_ROW_BYTES);
     };
     // GroupNorm (+ SiLU) of the staged chunk, in place, by the wave that staged it (its own DMA pieces: its own vmcnt wait covers them);
     // every piece of a lane holds the same logical 16-B chunk (h & 7 == (lane >> 3) & 7 whatever the piece), i.e. the same 8 channels
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
         for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
-            if (q >= q0 && q < q1 && q * 8 + wave < HPIECES) {
-                v8* a = (v8*)(d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES + lane * 16);
+            if (q >= q0 && q < q1 && q * NSTG + sw < HPIECES) {
+                v8* a = (v8*)(d + (q * NSTG + sw) * 8 * GEMM_ROW_BYTES + lane * 16);
                 const v8 t = *a;
                 v8 o;
 #pragma unroll
@@ -186,21 +197,45 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
 
     const int nsteps = 9 * cpt;
     // LDS-DMA instructions this wave issues per weight step / per halo (wave-uniform: the last round of pieces is ragged)
-    const int nW = (WQ - 1) + ((WQ - 1) * 8 + wave < WPIECES ? 1 : 0);
-    const int nH = (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
+    const int nW = (WQ - 1) + ((WQ - 1) * 8 + (wave & 7) < WPIECES ? 1 : 0);
+    const int nH = HWV ? 0 : (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
     auto step_ct = [&](int st) { return st / 9; };
     const bool gn = p.gn_tab != nullptr;
     if (gn) {                                           // this sample's (scale, shift) table -> LDS, before any LDS-DMA is in flight
         const f32x4* src = (const f32x4*)(p.gn_tab + (size_t)b * p.Cin * 2);
         f32x4* dst = (f32x4*)gtab;
-        for (int i = tid; i < p.Cin / 2; i += 512) dst[i] = src[i];
+        for (int i = tid; i < p.Cin / 2; i += NT) dst[i] = src[i];
         __syncthreads();
     }
-    stage_halo(0, 0);                                   // oldest: whoever waits for weight step 0 has the first halo too
+    if constexpr (HWV > 0) {
+        if (wave >= 8) {
+            // ------------------------------------------------------------------ halo wave: the input side of every chunk
+            constexpr int PPT = (HQ + 6) / 7;                   // pieces normalised per tap (taps 2 .. 8)
+            stage_halo(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gn) norm_halo(0, 0, 0, HQ);
+            for (int ct = 0; ct < cpt; ++ct) {
+#pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's in-place writes are in LDS ...
+                    __builtin_amdgcn_s_barrier();                        // ... before the step that may read them; the halo buffer
+                    asm volatile("" ::: "memory");                       // of chunk ct - 1 is free from (ct, tap 0) on
+                    if (ct + 1 < cpt) {
+                        if (tap == 0) stage_halo((ct + 1) & 1, ct + 1);
+                        if (tap == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // two steps of flight
+                        if (gn && tap >= 2) norm_halo((ct + 1) & 1, ct + 1, (tap - 2) * PPT, (tap - 1) * PPT);
+                    }
+                }
+            }
+            tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 512, 64 * HWV);
+            return;
+        }
+    }
+    if constexpr (HWV == 0) stage_halo(0, 0);           // oldest: whoever waits for weight step 0 has the first halo too
 #pragma unroll
     for (int j = 0; j < S - 1; ++j)
         if (j < nsteps) stage_w(j % S, step_ct(j), j - 9 * step_ct(j));
-    if (gn) {                                           // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
+    if (HWV == 0 && gn) {                               // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
         wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
         norm_halo(0, 0, 0, HQ);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written back before the barrier of step 0 publishes the halo
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
             // weight step `step` must have landed.  Younger loads that may stay in flight: the weight steps behind it (at most
             // S - 2) and the next chunk's halo if it was issued inside that window (at tap 0 of this chunk, taps 1 .. S - 1 ago)
             const int ahead = min(S - 2, nsteps - 1 - step);
-            const int halo_in_window = (tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
+            const int halo_in_window = (HWV == 0 && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
             wait_vmcnt_dyn(ahead * nW + halo_in_window);
             __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
             asm volatile("" ::: "memory");
@@ -221,12 +256,14 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
                 const int ns = step + S - 1, nct = step_ct(ns);
                 stage_w(ns % S, nct, ns - 9 * nct);                  // into the slot of step - 1
             }
-            if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
-            // ... and normalised in place once it has landed for this wave: the wait above stops counting it from tap S on (it is older
-            // than every weight step still in flight); the barrier of the next chunk's tap 0 publishes the result
-            // -- one piece per tap (taps S .. S + HQ - 1 <= 8), so that no step carries more than ~70 extra VALU instructions beside its
-            // 40 MFMAs per wave
-            if (gn && tap >= S && tap < S + HQ && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1, tap - S, tap - S + 1);
+            if constexpr (HWV == 0) {
+                if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
+                // ... and normalised in place once it has landed for this wave: the wait above stops counting it from tap S on (it is
+                // older than every weight step still in flight); the barrier of the next chunk's tap 0 publishes the result
+                // -- one piece per tap (taps S .. S + HQ - 1 <= 8), so that no step carries more than ~70 extra VALU instructions
+                // beside its 40 MFMAs per wave
+                if (gn && tap >= S && tap < S + HQ && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1, tap - S, tap - S + 1);
+            }
             const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES;
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
 #pragma unroll
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 1) void conv_halo_kernel(const Ge
     row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{});
     if (p.gn_out) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.N / 10, b, (ty * tiles_x + tx) * 4 + wm, nb, gna, FM, lane);
-    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+    if (HWV == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
 }
 
 // variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts;
@@ -306,9 +343,13 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     }
     const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * bn * GEMM_ROW_BYTES + (p.gn_tab ? p.Cin * 8 : 0);
     if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
-#define IMH_CH3(TT, FNV, FMV, SV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV>; static DynLdsOnce lds_once; \
+    // the fused GroupNorm front end runs on the form with four halo waves (the input side off the MFMA waves); g_halo_mode
+    // (imh_debug_set key 5, A/B): 1 forces the eight-wave form, 2 the halo-wave form for every launch
+    const bool hw4 = g_halo_mode == 2 || (g_halo_mode != 1 && p.gn_tab != nullptr);
+#define IMH_CH4(TT, FNV, FMV, SV, HV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
+        hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
+#define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) IMH_CH4(TT, FNV, FMV, SV, 4); else IMH_CH4(TT, FNV, FMV, SV, 0); } while (0)
 #define IMH_CH(TT) do { \
         if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
@@ -318,6 +359,7 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     else IMH_CH(f16_t);
 #undef IMH_CH
 #undef IMH_CH3
+#undef IMH_CH4
     return check_launch("conv_halo_kernel");
 }
 

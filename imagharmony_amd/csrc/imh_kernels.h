@@ -97,6 +97,7 @@ extern int g_attn_force_nw;
 extern int g_xattn_mode;
 extern int g_attn_mode;
 extern int g_xcd_mode;
+extern int g_halo_mode;
 
 struct SmallAttnParams {
     const void* Q; const void* K; const void* V; void* O;

@@ -270,6 +270,15 @@ def test_conv_with_fused_groupnorm_silu(L, dtype, case):
         n = ctx.gn_apply(x.view(B, H * W, Cin), tab, silu).view(B, H, W, Cin)
         y2 = ctx.conv3x3(n, pack_conv(w4), bias=bias, cfg=cfg).view(B * H * W, Cout)
         assert torch.equal(y2, y), "in-kernel apply and the apply pass round the same values"
+        # the two workgroup forms (imh_debug_set key 5): 1 = eight do-everything waves, 2 = eight MFMA waves + four halo waves (the
+        # default for fused launches); same arithmetic, same bits -- with and without the fused front end
+        try:
+            for mode in (1, 2):
+                assert L.load().imh_debug_set(5, mode) == 0
+                assert torch.equal(ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, silu)).view(B * H * W, Cout), y), f"halo mode {mode}"
+                assert torch.equal(ctx.conv3x3(n, pack_conv(w4), bias=bias, cfg=cfg).view(B * H * W, Cout), y), f"halo mode {mode}, plain conv"
+        finally:
+            L.load().imh_debug_set(5, 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

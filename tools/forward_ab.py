@@ -40,6 +40,8 @@ CONFIGS = collections.OrderedDict([
     # GroupNorm + SiLU + concat inside the LDS-halo convs (round 4) vs table + apply passes + materialised concats
     ("gn_unfused", dict(gn_fuse=False)),
     ("gn_fused", dict(gn_fuse=True)),
+    ("gn_fused_w8", dict(gn_fuse=True, halo=1)),      # imh_debug_set key 5: 1 = the eight-wave conv form for the fused launches too
+    ("halo_w12", dict(gn_fuse=True, halo=2)),         # 2 = four halo waves for every LDS-halo conv
     # self-attention projections: the two-problem launch of round 3 vs ONE wave-specialised [Q|K|V] launch (at both widths / at C = 1280 only)
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
@@ -72,6 +74,7 @@ def main():
         lib.imh_debug_set(3, int(c.get("xattn", 0)))
         lib.imh_debug_set(4, int(c.get("attn", 0)))
         lib.imh_debug_set(2, int(c.get("xcd", 0)))
+        lib.imh_debug_set(5, int(c.get("halo", 0)))
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
@@ -89,6 +92,7 @@ def main():
             lib.imh_debug_set(3, int(c.get("xattn", 0)))
             lib.imh_debug_set(4, int(c.get("attn", 0)))
             lib.imh_debug_set(2, int(c.get("xcd", 0)))
+            lib.imh_debug_set(5, int(c.get("halo", 0)))
             ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
@@ -102,6 +106,7 @@ def main():
     lib.imh_debug_set(3, 0)
     lib.imh_debug_set(4, 0)
     lib.imh_debug_set(2, 0)
+    lib.imh_debug_set(5, 0)
     out = {}
     for n in names:
         rec, c = plans[n]
