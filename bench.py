@@ -144,20 +144,21 @@ def cpu_baseline(res, ip_tokens, denoise_steps):
     return out
 
 
-def configs3_extra(device, res_px, S=4, T=16, steps=50):
+def configs3_extra(device, res_px, S=4, T=16, steps=50, dtype=torch.float16, n_embeds=1, note=None):
     """BASELINE.json configs[3]: SDXL 1024^2, 50 steps, batch 4 per GPU (S candidates stacked into one UNet batch of 2S with
     CFG), Resampler num_queries = 16 (the 16 image tokens come out of the IP-Adapter-Plus-XL Resampler on the device:
-    ip_adapter.py:392-403), fp16.  Own fp16 UNet (random weights) + engine; one warm-up denoise, one timed."""
+    ip_adapter.py:392-403), fp16.  Own UNet (random weights) + engine; one warm-up denoise, one timed.
+    configs[4] is the same harness at bf16, 30 steps, T = 32 = two 16-token image embeds (dual-category edit, n_embeds = 2)."""
     from imagharmony_amd import pns
     from imagharmony_amd.modules import Resampler
     from imagharmony_amd.pipeline import StableDiffusionXLCustomPipeline
     from imagharmony_amd.schedulers import DDIMScheduler
-    dtype = torch.float16
     unet = build_unet(device, dtype, T)
-    rs = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=T, embedding_dim=1280, output_dim=2048, ff_mult=4).to(device, dtype).eval()
-    clip = torch.randn(2, 257, 1280, generator=torch.Generator("cpu").manual_seed(5)).to(device, dtype)
-    with torch.no_grad():
-        ip = rs(clip).float().cpu()                       # [2, T, 2048]: image tokens of the positive / negative branch
+    q = T // n_embeds
+    rs = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=q, embedding_dim=1280, output_dim=2048, ff_mult=4).to(device, dtype).eval()
+    with torch.no_grad():                                 # [2, T, 2048]: image tokens of the positive / negative branch, one Resampler
+        ip = torch.cat([rs(torch.randn(2, 257, 1280, generator=torch.Generator("cpu").manual_seed(5 + j)).to(device, dtype)).float().cpu()
+                        for j in range(n_embeds)], 1)     # call per image embed (ip_adapter.py:405-417), tokens concatenated
     pe, ne, po, no = synthetic_conditioning(T)
     pe[:, 77:], ne[:, 77:] = ip[:1], ip[1:]
     pe, ne, po, no = [t.to(device) for t in (pe, ne, po, no)]
@@ -173,8 +174,8 @@ def configs3_extra(device, res_px, S=4, T=16, steps=50):
     torch.cuda.synchronize(device)
     dt_s = time.perf_counter() - t0
     out = {"images_per_sec": S / dt_s, "ms_per_unet_forward": dt_s / steps * 1e3, "unet_batch": 2 * S, "denoise_steps": steps,
-           "ip_tokens": T, "dtype": "fp16", "scheduler": "DDIM", "outputs_finite": bool(torch.isfinite(o).all().item()),
-           "note": "BASELINE.json configs[3] on one GPU (never `value`): the 16 image tokens are produced by the Resampler on the "
+           "ip_tokens": T, "dtype": "fp16" if dtype == torch.float16 else "bf16", "scheduler": "DDIM", "outputs_finite": bool(torch.isfinite(o).all().item()),
+           "note": note or "BASELINE.json configs[3] on one GPU (never `value`): the 16 image tokens are produced by the Resampler on the "
                    "device; parity of this shape family: tests/test_gpu_parity_fullsize.py (UNet batch 8, T = 16, fp16 vs the CPU oracle)"}
     del e, pipe, unet, rs
     torch.cuda.empty_cache()
@@ -288,6 +289,62 @@ def ip_attn_cfg4(device, dtype, reps=20):
             "shape": f"UNet batch {B} (4 candidates x CFG), L = {Lq}, C = {C_}, {T} image tokens",
             "note": f"{reps} back-to-back calls (warm operands), HIP events around the recorded plan; K/V projections of the conditioning "
                     "are step-invariant and not in the timed call"}
+
+
+def box_calibration(device, dtype, reps=20):
+    """one FIXED launch timed on this box, so that numbers from different boxes / rounds can be normalised (the same build measures
+    20.5-23.1 ms per forward from box to box): the 8192 x 5120 x 2560 GEMM on the wave-specialised 256 x 160 kernel (variant 23256),
+    `reps` back-to-back launches from a recorded plan between two HIP events"""
+    from imagharmony_amd.ctx import Ctx
+    M, N, K = 8192, 5120, 2560
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(M, K, generator=g).to(device, dtype)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(device, dtype)
+    y = torch.empty(M, N, device=device, dtype=dtype)
+    rec = Ctx(device, dtype, record=True)
+    for _ in range(reps):
+        rec.gemm(x, w, out=y, cfg=(23256, 160, 1), descr="calibration")
+    rec.run(); torch.cuda.synchronize(device)
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rec.run(); e1.record(); torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        best = us if best is None else min(best, us)
+    fl = 2.0 * M * N * K
+    return {"launch": "imh::gemm_ws_kernel 256x160 (variant 23256), 8192 x 5120 x 2560, bf16 random operands", "us": best,
+            "tflops": fl / (best * 1e-6) / 1e12, "reference_us": 186.0,
+            "note": "reference_us = the same launch on the round-3 profile box (profiles/r03_pmc_sq_gemm_attn.md); us / reference_us "
+                    "scales this box against it"}
+
+
+def pns_two_stage(eng, pipe, device, lat_shape, N=8, preview_steps=10, final_steps=30):
+    """the two-stage schedule of assets/1.png / README.md:27 on ONE rank, end to end: N candidate seeds x a `preview_steps` denoise,
+    the judge, then the judged-best noise x the full `final_steps` denoise -- so that the serial tail of the scheme is a number
+    (at W ranks with N = W the tail runs on the owner rank while the others idle: (N * p + f) / (p + f) is the ceiling of the
+    speed-up, 2.75x for 8 x 10 + 30).  Uses the latent-statistic judge (off the measured path's critical work, like bench `value`)."""
+    from imagharmony_amd import pns
+    prev = eng.fork()
+    prev.set_schedule(pipe.scheduler, preview_steps)
+    noises = [pns.seed_latents(5000 + j, lat_shape).to(device) for j in range(N)]
+    prev.denoise(noises[0]); eng.denoise(noises[0])            # plans recorded / captured outside the timed region
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    scores = [pns.default_scorer(prev.denoise(z)) for z in noises]
+    best = int(torch.argmax(torch.cat(scores)))            # (reads the scores back: the previews are done)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    out = eng.denoise(noises[best])
+    torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    fw = N * preview_steps + final_steps
+    return {"N": N, "preview_steps": preview_steps, "final_steps": final_steps, "seconds_per_pns_run": t2 - t0,
+            "final_images_per_sec": 1.0 / (t2 - t0), "preview_seconds": t1 - t0, "final_seconds": t2 - t1, "unet_forwards": fw,
+            "ms_per_unet_forward": (t2 - t0) / fw * 1e3, "serial_tail_share_at_8_ranks": (t2 - t1) / ((t1 - t0) / N + (t2 - t1)),
+            "ceiling_speedup_8_ranks": (t2 - t0) / ((t1 - t0) / N + (t2 - t1)), "outputs_finite": bool(torch.isfinite(out).all().item()),
+            "note": "one rank runs all N previews back to back, then the final denoise; at 8 ranks the previews shard 8 ways and the "
+                    "final denoise stays on the owner rank (pns.run_pns) unless its CFG halves are split over two ranks "
+                    "(pns.cfg_split_denoise)"}
 
 
 def _self_launch(n, script=None, argv=None):
@@ -531,6 +588,25 @@ def main():
                 res["configs3_fp16_50steps_batch4_T16"] = configs3_extra(device, a.res)
             except Exception as e:      # noqa: BLE001
                 res["configs3_fp16_50steps_batch4_T16"] = {"error": f"{type(e).__name__}: {e}"}
+            # ... and configs[4]'s single-GPU shape: 4 candidates per GPU, two 16-token image embeds (T = 32), 30 steps, bf16 attention
+            # (fp8 attention declined on measured grounds, profiles/r03_fp8_attention_decision.md)
+            try:
+                res["configs4_bf16_30steps_batch4_T32"] = configs3_extra(
+                    device, a.res, S=4, T=32, steps=30, dtype=torch.bfloat16, n_embeds=2,
+                    note="BASELINE.json configs[4] on one GPU (never `value`): dual-category edit, two Resampler image embeds of 16 tokens, "
+                         "4 PNS candidates stacked per forward, bf16 attention; parity of this shape: tests/test_gpu_parity_fullsize.py "
+                         "(UNet batch 8, T = 32, bf16 vs the CPU oracle)")
+            except Exception as e:      # noqa: BLE001
+                res["configs4_bf16_30steps_batch4_T32"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and a.stacked > 1:
+            try:
+                res["box_calibration"] = box_calibration(device, dtype)
+            except Exception as e:      # noqa: BLE001
+                res["box_calibration"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                res["pns_two_stage"] = pns_two_stage(eng, pipe, device, lat_shape)
+            except Exception as e:      # noqa: BLE001
+                res["pns_two_stage"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
             try:
                 from imagharmony_amd.vae import AutoencoderKL, decode_latents
@@ -549,6 +625,11 @@ def main():
                 res["vae_decode"] = {"ms_per_image": ms_v, "outputs_finite": bool(torch.isfinite(img).all().item()),
                                      "note": "SDXL VAE decoder 128x128 latent -> 1024x1024 image on the HIP kernels (random weights), "
                                              "eager launches; not part of `value`"}
+                per_img = dt / images
+                res["value_with_decode"] = {
+                    "untiled": 1.0 / (per_img + ms_v["untiled"] * 1e-3), "tiled": 1.0 / (per_img + ms_v["tiled"] * 1e-3), "unit": "images/sec",
+                    "note": "decoded images per second = `value`'s denoise time + the measured VAE decode of the same latent, serially on this "
+                            "GPU (the reference returns PIL images: custom_pipelines.py:365-386, test.py:73 enables VAE tiling)"}
                 del vae
             except Exception as e:      # noqa: BLE001
                 res["vae_decode"] = {"error": f"{type(e).__name__}: {e}"}

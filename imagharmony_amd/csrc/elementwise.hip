@@ -12,6 +12,8 @@
 //   EW_SOFTMAX    row softmax of fp32 scores -> T probabilities (the VAE mid-block attention: one head of width
 //                 512 over 4096-16384 tokens, materialised as GEMM -> softmax -> GEMM; once per image)
 //   EW_ROW_STATS  (sum, M2) of token rows, the stand-alone LayerNorm-statistics producer (imh_lnstats.h)
+//   EW_STEP_ROW   y[0:n] = a[*step * n + 0:n]: the denoise step's row of a per-schedule table (the stacked time-embedding projections,
+//                 computed once per schedule for all steps instead of five launches per step)
 //   EW_CAST_F32   T -> fp32 copy (debug / host-side plumbing)
 //   EW_STEP_SET   the device-resident step counter (lets 30 graph replays run with no host updates)
 // Per-step scalars (timestep, scheduler coefficients, input scale) may come from device tables
@@ -24,7 +26,7 @@
 namespace imh {
 
 enum : int { EW_TIMESTEP = 0, EW_SILU = 1, EW_CONCAT = 2, EW_CONV_IN = 3, EW_CFG_STEP = 4, EW_CAST_F32 = 5,
-             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8, EW_SOFTMAX = 9, EW_ROW_STATS = 10 };
+             EW_ADD = 6, EW_STEP_SET = 7, EW_CFG_RESCALE = 8, EW_SOFTMAX = 9, EW_ROW_STATS = 10, EW_STEP_ROW = 11 };
 
 // a: fp32 values [n_vals]; y: T [n_vals, dim]; cos first, then sin.
 template <typename T>
@@ -237,6 +239,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const EwParams p) {
     }
 }
 
+template <typename T>
+__global__ void step_row_kernel(const EwParams p) {
+    typedef typename Vec<T>::v8 v8;
+    const long long nv = p.n >> 3;
+    const v8* src = (const v8*)p.a + (long long)(*p.step) * nv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) ((v8*)p.y)[i] = src[i];
+}
+
 __global__ void step_set_kernel(int* step, int value, int set) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step = set ? value : *step + 1;
 }
@@ -327,6 +337,10 @@ static int ew_typed(int op, const EwParams& p, hipStream_t stream) {
         case EW_ROW_STATS:
             if (p.n <= 0 || p.i0 <= 0 || (p.i0 & 7) || (p.i1 & 7) || !p.a) { set_error("row_stats: rows=%lld C=%d ld=%d (C and ld must be multiples of 8)", p.n, p.i0, p.i1); return IMH_ERR_SHAPE; }
             hipLaunchKernelGGL((row_stats_kernel<T>), dim3((unsigned)((p.n + 3) / 4)), dim3(256), 0, stream, p);
+            break;
+        case EW_STEP_ROW:
+            if (p.n <= 0 || (p.n & 7) || !p.a || !p.step) { set_error("step_row: n=%lld must be a positive multiple of 8, a and step non-null", p.n); return IMH_ERR_ARG; }
+            hipLaunchKernelGGL((step_row_kernel<T>), dim3(grid_for(p.n >> 3, 256)), dim3(256), 0, stream, p);
             break;
         case EW_STEP_SET:
             hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(64), 0, stream, (int*)p.y, p.i0, p.i1);

@@ -108,6 +108,9 @@ class DenoiseEngine:
         st = self.st
         if st.latents is None or tuple(st.latents.shape) != (self.S, 4, self.H, self.W):
             st.latents = torch.zeros(self.S, 4, self.H, self.W, dtype=torch.float32, device=self.device)
+        # the time-embedding rows of every step of this schedule under this conditioning: once here, not five launches per step
+        self._temb_ctx = Ctx(self.device, self.dtype)          # (its pool owns the table for the life of the plan)
+        self.unet.precompute_temb(self._temb_ctx, st, st.t_table)
         rec = Ctx(self.device, self.dtype, record=True)
         out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
         rec.tag = 70

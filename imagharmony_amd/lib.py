@@ -16,7 +16,7 @@ GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
 GN_ALL, GN_STATS, GN_TABLE, GN_APPLY = 0, 1, 2, 3
 (EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX,
- EW_ROW_STATS) = range(11)
+ EW_ROW_STATS, EW_STEP_ROW) = range(12)
 
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 

@@ -474,6 +474,7 @@ class StepState:
         self.aug_emb = None        # [B, time_embed_dim]  add_embedding(text_embeds ++ time_ids) (step-invariant)
         self.kv = None             # {attn2 processor name: KVCache}
         self.temb_all = None       # [B, sum Cout] stacked time_emb_proj output (per step)
+        self.temb_table = None     # [steps, B * sum Cout] the same for EVERY step of the schedule (precompute_temb), or None
         self.t_value = None        # fp32 [B] explicit timestep values (eager forward)
 
 
@@ -609,6 +610,37 @@ class UNet2DConditionModel(nn.Module):
             self._imh_temb = c
         return c[1], c[2]
 
+    def _temb_chain(self, ctx, tsin, aug):
+        """time_embedding(t) + aug_emb -> SiLU -> the 17 stacked time_emb_proj Linears: [rows, 320] -> [rows, sum Cout]"""
+        te = self.time_embedding
+        h = ctx.gemm(tsin, _w(te.linear_1, ctx), bias=_b(te.linear_1, ctx), flags=L.GF_ACT_SILU, descr="time_emb.1")
+        # emb = time_embedding(t) + aug_emb, then SiLU (every ResnetBlock2D applies it before time_emb_proj)
+        emb = ctx.gemm(h, _w(te.linear_2, ctx), bias=_b(te.linear_2, ctx), residual=aug, descr="time_emb.2")
+        semb = ctx.silu(emb, descr="silu(emb)")
+        wt, bt = self._temb_stack(ctx)
+        out = ctx.gemm(semb, wt, bias=bt, descr="time_emb_proj(all)")
+        ctx.free(h); ctx.free(emb); ctx.free(semb)
+        return out
+
+    @torch.no_grad()
+    def precompute_temb(self, ctx, st, timesteps):
+        """st.temb_table = the stacked time-embedding projections of EVERY step of a schedule ([steps, B * sum Cout]; row i = what
+        the per-step chain yields at timestep i): they depend on the step and on the conditioning (aug_emb), not on the latent,
+        so a denoise loop computes them once per (schedule, conditioning) instead of five launches per step (r03 DESIGN 9.4)."""
+        B = st.aug_emb.shape[0]
+        ts = timesteps.to(device=ctx.device, dtype=torch.float32).reshape(-1)
+        n = ts.numel()
+        tv = ts.repeat_interleave(B).contiguous()                      # row i * B + b -> timestep i
+        tsin = ctx.new(n * B, self.config.block_out_channels[0])
+        ctx.ew(L.EW_TIMESTEP, tsin, a=tv, n=n * B, i=(self.config.block_out_channels[0], 0, 0, 0, 0, 0), descr="time_proj(all steps)")
+        aug = st.aug_emb.repeat(n, 1).contiguous()                     # plumbing: the residual rows of every step
+        tab = self._temb_chain(ctx, tsin, aug)
+        ctx.free(tsin)
+        st.temb_table = tab.view(n, B * self.temb_total)
+        if ctx.record:
+            ctx.keep.extend([tv, aug])
+        return st.temb_table
+
     # ---- step-invariant conditioning ----
     @torch.no_grad()
     def prepare_conditioning(self, ctx, encoder_hidden_states, text_embeds, time_ids, st=None):
@@ -651,19 +683,20 @@ class UNet2DConditionModel(nn.Module):
             raise L.ImhError(f"latent {Hl}x{Wl}: sides must be multiples of {div} (image sides multiples of {8 * div})")
         # -- time embedding --
         ctx.tag = 1
-        tsin = ctx.new(B, boc[0])
-        if st.t_table is not None:
-            ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_table, step=st.step, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
+        if st.temb_table is not None and st.t_table is not None and st.temb_table.shape[1] == B * self.temb_total:
+            # the chain below depends on the step and the conditioning only, not on the latent: all steps' rows were computed once
+            # per schedule (precompute_temb); the step's row is copied in (one launch instead of five)
+            st.temb_all = ctx.new(B, self.temb_total)
+            ctx.ew(L.EW_STEP_ROW, st.temb_all, a=st.temb_table, step=st.step, n=B * self.temb_total, descr="temb_row(step)",
+                   nbytes=2.0 * B * self.temb_total * st.temb_all.element_size())
         else:
-            ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_value, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
-        te = self.time_embedding
-        h = ctx.gemm(tsin, _w(te.linear_1, ctx), bias=_b(te.linear_1, ctx), flags=L.GF_ACT_SILU, descr="time_emb.1")
-        # emb = time_embedding(t) + aug_emb, then SiLU (every ResnetBlock2D applies it before time_emb_proj)
-        emb = ctx.gemm(h, _w(te.linear_2, ctx), bias=_b(te.linear_2, ctx), residual=st.aug_emb, descr="time_emb.2")
-        semb = ctx.silu(emb, descr="silu(emb)")
-        wt, bt = self._temb_stack(ctx)
-        st.temb_all = ctx.gemm(semb, wt, bias=bt, descr="time_emb_proj(all)")
-        ctx.free(tsin); ctx.free(h); ctx.free(emb); ctx.free(semb)
+            tsin = ctx.new(B, boc[0])
+            if st.t_table is not None:
+                ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_table, step=st.step, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
+            else:
+                ctx.ew(L.EW_TIMESTEP, tsin, a=st.t_value, n=B, i=(boc[0], 0, 0, 0, 0, 0), descr="time_proj")
+            st.temb_all = self._temb_chain(ctx, tsin, st.aug_emb)
+            ctx.free(tsin)
         # -- conv_in (+ CFG duplication + scale_model_input) --
         ctx.tag = 2
         x = ctx.new(B, Hl, Wl, boc[0])

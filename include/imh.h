@@ -316,7 +316,8 @@ enum imh_ew_op {
     IMH_EW_CFG_RESCALE = 8, /* y[s] = f3 * std(eps_text_s) / std(eps_cfg_s) + 1 - f3 (rescale_noise_cfg, custom_pipelines.py:351-354);
                              * a = noise prediction NHWC [2 i0, i1, 4], f2 = guidance scale; IMH_EW_CFG_STEP reads y through `w` */
     IMH_EW_SOFTMAX = 9,     /* y[r,:] (T) = softmax(f0 * a[r,:]) with a fp32 (VAE mid-block attention); i0 rows, i1 cols, i2 / i3 leading dims */
-    IMH_EW_ROW_STATS = 10   /* y[r] (fp32 pair) = (sum, M2) of a[r, 0:i0] (row stride i1), n rows: LayerNorm statistics in the ln_stats format, one slot */
+    IMH_EW_ROW_STATS = 10,  /* y[r] (fp32 pair) = (sum, M2) of a[r, 0:i0] (row stride i1), n rows: LayerNorm statistics in the ln_stats format, one slot */
+    IMH_EW_STEP_ROW = 11    /* y[0:n] = a[*step * n + 0:n] (T; n % 8 == 0): row `step` of a per-schedule table (time embeddings of all denoise steps) */
 };
 
 typedef struct imh_ew_args {
