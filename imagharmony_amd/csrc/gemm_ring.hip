@@ -658,7 +658,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         if ((p.flags & ~(GF_LN_ROW | GF_GEGLU)) == 0 && pre.ok && have_pre) {
             constexpr int NV = 4 * FN;
             const bool geglu = p.flags & GF_GEGLU;
-            if (!p.bias) {
+            const bool hb = p.bias != nullptr;          // (the transformer blocks' launches carry none: the GEGLU bias lives in ln_c)
+            if (!hb) {
 #pragma unroll
                 for (int q = 0; q < NV; ++q) pre.bias[q] = 0.f;
             }
@@ -709,8 +710,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                     }
                 if (geglu) {
                     float o[NV / 2];
-#pragma unroll
-                    for (int q = 0; q < NV / 2; ++q) o[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
+                    geglu_quads<NV>(v, o);
                     stv<T, NV / 2>((T*)p.Y + (size_t)m * p.ldy + (nb >> 1), o);
                 } else {
                     stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);

@@ -100,20 +100,66 @@ template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
-// exact-erf GELU (diffusers GEGLU / nn.GELU()) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far
-// below bf16/fp16 output resolution): 1 rcp + 1 exp + 7 fma instead of libm erff's ~40 instructions.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float e = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(e, x);
+// erf-GELU (diffusers GEGLU / nn.GELU(): 0.5 x (1 + erf(x / sqrt 2))) WITHOUT transcendentals: erf(x / sqrt 2) = x Q(x^2) on
+// |x| <= 3.3 sqrt 2 (clamped; 1 - erf(3.3) = 3e-6), Q a degree-10 minimax fit evaluated by Horner in u = 2 x^2 / xmax^2 - 1 (in [-1, 1]:
+// well conditioned in fp32).  |erf error| <= 5.1e-6, |GELU error| <= 1.2e-5 over all x in fp32 -- two orders below bf16 / fp16
+// output resolution.  Only FMAs, so two gates go through one v_pk_fma_f32 stream (gelu2): ~8.5 VALU issues per gate instead of
+// 14 + v_rcp + v_exp (Abramowitz-Stegun 7.1.26, rounds 1-3) -- the GEGLU epilogue of ff.net.0 evaluates 160 gates per lane per tile.
+// (fit: tools/fit_gelu_poly.py)
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+#define GELU_Q0 0.3027370870113373f
+#define GELU_Q1 -0.1496594101190567f
+#define GELU_Q2 0.10756179690361023f
+#define GELU_Q3 -0.08084674924612045f
+#define GELU_Q4 0.05918922647833824f
+#define GELU_Q5 -0.04226003959774971f
+#define GELU_Q6 0.02678486704826355f
+#define GELU_Q7 -0.012068570591509342f
+#define GELU_Q8 0.00669495714828372f
+#define GELU_Q9 -0.006969131994992495f
+#define GELU_Q10 0.003111163154244423f
+constexpr float GELU_XMAX = 4.666904755831214f;              // 3.3 * sqrt(2)
+constexpr float GELU_UA = 2.0f / (GELU_XMAX * GELU_XMAX);
+__device__ __forceinline__ constexpr float gelu_coef(int i) {
+    // Q(u) = sum_i c_i u^i, highest degree first
+    constexpr float c[11] = {GELU_Q10, GELU_Q9, GELU_Q8, GELU_Q7, GELU_Q6, GELU_Q5, GELU_Q4, GELU_Q3, GELU_Q2, GELU_Q1, GELU_Q0};
+    return c[i];
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -GELU_XMAX, GELU_XMAX);
+    const float u = __builtin_fmaf(xc * xc, GELU_UA, -1.0f);
+    float q = gelu_coef(0);
+#pragma unroll
+    for (int i = 1; i <= 10; ++i) q = __builtin_fmaf(q, u, gelu_coef(i));
+    const float h = 0.5f * x;
+    return __builtin_fmaf(h, xc * q, h);
+}
+// two gates at once on packed fp32 (plain even-aligned register pairs, broadcast constants: no op_sel low-lane selects)
+__device__ __forceinline__ f32x2v gelu2(f32x2v x) {
+    f32x2v xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -GELU_XMAX, GELU_XMAX);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -GELU_XMAX, GELU_XMAX);
+    const f32x2v ua = {GELU_UA, GELU_UA}, m1 = {-1.0f, -1.0f};
+    const f32x2v u = __builtin_elementwise_fma(xc * xc, ua, m1);
+    f32x2v q = {gelu_coef(0), gelu_coef(0)};
+#pragma unroll
+    for (int i = 1; i <= 10; ++i) { const f32x2v c = {gelu_coef(i), gelu_coef(i)}; q = __builtin_elementwise_fma(q, u, c); }
+    const f32x2v hf = {0.5f, 0.5f};
+    const f32x2v h = x * hf;
+    return __builtin_elementwise_fma(h, xc * q, h);
+}
+// GEGLU over a lane's NV consecutive pre-activation columns, interleaved in QUADS (value_2k, value_2k+1, gate_2k, gate_2k+1) -- the two
+// gates of a quad sit in one even-aligned accumulator pair: o[2k], o[2k+1] = v[4k], v[4k+1] * gelu(v[4k+2], v[4k+3])
+template <int NV>
+__device__ __forceinline__ void geglu_quads(const float* v, float* o) {
+    static_assert(NV % 4 == 0, "whole quads per lane");
+#pragma unroll
+    for (int k = 0; k < NV / 4; ++k) {
+        const f32x2v val = {v[4 * k], v[4 * k + 1]}, gate = {v[4 * k + 2], v[4 * k + 3]};
+        const f32x2v r = val * gelu2(gate);
+        o[2 * k] = r[0]; o[2 * k + 1] = r[1];
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -50,7 +50,7 @@ inline void xcd_partition(GemmParams& p, int bm, int bn, int* grid) {
 }
 
 enum : int {
-    GF_GEGLU = 1,      // columns interleaved (value, gate): out[n/2] = a * gelu(g)
+    GF_GEGLU = 1,      // columns interleaved in quads (value, value, gate, gate): out[2k], out[2k+1] = v[4k], v[4k+1] * gelu(v[4k+2], v[4k+3])
     GF_ACT_GELU = 2,   // exact-erf GELU on the (biased) result
     GF_ACT_SILU = 4,
     GF_VT_PERM = 8,    // permute each 16-column group [0-3,8-11,4-7,12-15] (attention V^T layout)
@@ -221,10 +221,14 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, float (&
 #pragma unroll
         for (int q = 0; q < NV; ++q) v[q] = silu_f(v[q]);
     }
-    if (geglu) {       // (value, gate) pairs -> NH outputs at column nb/2 of an [M, N/2] result
+    if (geglu) {       // (value, value, gate, gate) quads -> NH outputs at column nb/2 of an [M, N/2] result
         const int ob = nb >> 1, NO = N >> 1;
+        {
+            float o2[NH];
+            geglu_quads<NV>(v, o2);
 #pragma unroll
-        for (int q = 0; q < NH; ++q) v[q] = v[2 * q] * gelu_erf_f(v[2 * q + 1]);
+            for (int q = 0; q < NH; ++q) v[q] = o2[q];
+        }
         T* y = (T*)p.Y + (size_t)m * p.ldy + ob;
         if (fast) {
             if (res && use_pre) {

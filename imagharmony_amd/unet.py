@@ -176,20 +176,27 @@ class Attention(nn.Module):
                               attention_mask=attention_mask)
 
 
+def geglu_interleave(t):
+    """[2 * inner, ...] = [values; gates] (diffusers GEGLU.proj: hidden, gate = proj(x).chunk(2)) -> rows in quads (value_2k,
+    value_2k+1, gate_2k, gate_2k+1): one output tile holds both halves and the two gates of a quad land in one even-aligned
+    accumulator register pair of the MFMA tile (IMH_GF_GEGLU: packed-fp32 GELU on both at once)"""
+    inner = t.shape[0] // 2
+    v, g = t[:inner].reshape((inner // 2, 2) + tuple(t.shape[1:])), t[inner:].reshape((inner // 2, 2) + tuple(t.shape[1:]))
+    return torch.cat([v, g], 1).reshape((2 * inner,) + tuple(t.shape[1:])).contiguous()
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim, inner):
         super().__init__()
         self.proj = Linear(dim, inner * 2)
 
     def packed(self, ctx):
-        """rows interleaved (value_q, gate_q) so one output tile holds both halves (GF_GEGLU epilogue)."""
+        """rows interleaved in (value, value, gate, gate) quads (geglu_interleave; GF_GEGLU epilogue)."""
         key = (_vkey(self.proj.weight, self.proj.bias), ctx.dtype, str(ctx.device))
         c = getattr(self, "_imh_packed", None)
         if c is None or c[0] != key:
             w, b = self.proj.weight.detach(), self.proj.bias.detach()
-            inner = w.shape[0] // 2
-            wi = torch.stack([w[:inner], w[inner:]], 1).reshape(2 * inner, -1)
-            bi = torch.stack([b[:inner], b[inner:]], 1).reshape(2 * inner)
+            wi, bi = geglu_interleave(w), geglu_interleave(b)
             c = (key, wi.to(device=ctx.device, dtype=ctx.dtype).contiguous(),
                  bi.to(device=ctx.device, dtype=ctx.dtype).contiguous())
             self._imh_packed = c
@@ -197,16 +204,17 @@ class GEGLU(nn.Module):
 
 
 def _geglu_packed_ln(self, ctx, norm):
-    """GEGLU projection with LayerNorm folded in (see attention_processor.fold_ln), rows interleaved (value, gate)."""
+    """GEGLU projection with LayerNorm folded in (see attention_processor.fold_ln), rows interleaved in quads (geglu_interleave)."""
     from .attention_processor import fold_ln
     key = (_vkey(self.proj.weight, self.proj.bias, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
     c = getattr(self, "_imh_packed_ln", None)
     if c is None or c[0] != key:
         wg, s, cc = fold_ln(self.proj.weight, norm, ctx)
-        inner = wg.shape[0] // 2
-        il = lambda t: torch.stack([t[:inner], t[inner:]], 1).reshape((2 * inner,) + tuple(t.shape[1:])).contiguous()
-        b = self.proj.bias.detach().to(device=ctx.device, dtype=ctx.dtype)
-        c = (key, il(wg), il(b), il(s), il(cc))
+        il = geglu_interleave
+        # the Linear's bias rides in the fold's constant term, c = W beta + b (fp32): one epilogue operand (and twenty live
+        # registers per lane of the 256 x 160 kernel's epilogue) less than a separate bias vector
+        b = self.proj.bias.detach().to(device=ctx.device, dtype=torch.float32)
+        c = (key, il(wg), None, il(s), il(cc + b))
         self._imh_packed_ln = c
     return c[1], c[2], c[3], c[4]
 

@@ -46,8 +46,9 @@ enum imh_dtype { IMH_DT_BF16 = 0, IMH_DT_F16 = 1 };
 
 /* epilogue flags of imh_gemm_args.flags */
 enum imh_gemm_flags {
-    IMH_GF_GEGLU = 1,     /* columns interleaved (value, gate); out[n/2] = a * gelu(g)  (diffusers GEGLU) */
-    IMH_GF_ACT_GELU = 2,  /* exact-erf GELU (resampler.py:18) */
+    IMH_GF_GEGLU = 1,     /* diffusers GEGLU: W rows interleaved in quads (value_2k, value_2k+1, gate_2k, gate_2k+1);
+                           * out[2k], out[2k+1] = value * gelu(gate); N % 16 == 0, Y is [M, N/2] */
+    IMH_GF_ACT_GELU = 2,  /* erf GELU, nn.GELU() (resampler.py:18); |error| <= 1.2e-5 (csrc/imh_common.h gelu_erf_f) */
     IMH_GF_ACT_SILU = 4,  /* SiLU (TimestepEmbedding) */
     IMH_GF_VT_PERM = 8,   /* write the attention V^T key permutation (see imh_attention) */
     IMH_GF_OUT_F32 = 16,  /* fp32 output */

@@ -31,6 +31,12 @@ def rnd(*shape, dtype, seed, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
 
 
+def geglu_ref(full):
+    """GF_GEGLU on pre-activations whose columns are interleaved in (value, value, gate, gate) quads"""
+    q = full.reshape(full.shape[0], -1, 4)
+    return (q[:, :, :2] * F.gelu(q[:, :, 2:])).reshape(full.shape[0], -1)
+
+
 def assert_close(y, ref, dtype, what, k=4.0):
     ref = ref.float()
     y = y.float()
@@ -95,7 +101,7 @@ def test_gemm_wave_specialised_folded_layernorm_geglu(L, dtype, cfg):
         y = ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=cfg)
         assert_close(y, full, dtype, f"folded LN {cfg} {(M, N, K)}", k=6.0)
         g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg)
-        assert_close(g, full[:, 0::2] * F.gelu(full[:, 1::2]), dtype, f"folded LN + GEGLU {cfg} {(M, N, K)}", k=8.0)
+        assert_close(g, geglu_ref(full), dtype, f"folded LN + GEGLU {cfg} {(M, N, K)}", k=8.0)
         assert torch.equal(g, ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg))
     for pp in [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]:
         with pytest.raises(L.ImhError, match="folded LayerNorm"):
@@ -139,8 +145,8 @@ def test_gemm_geglu(L, dtype, cfg):
     x = rnd(M, K, dtype=dtype, seed=1)
     w, b = rnd(2 * inner, K, dtype=dtype, seed=2, scale=K ** -0.5), rnd(2 * inner, dtype=dtype, seed=3)
     r = rnd(M, inner, dtype=dtype, seed=4)
-    wi = torch.stack([w[:inner], w[inner:]], 1).reshape(2 * inner, K).contiguous()
-    bi = torch.stack([b[:inner], b[inner:]], 1).reshape(2 * inner).contiguous()
+    from imagharmony_amd.unet import geglu_interleave
+    wi, bi = geglu_interleave(w), geglu_interleave(b)
     y = ctx.gemm(x, wi, bias=bi, flags=L.GF_GEGLU, residual=r, cfg=cfg)
     full = x.float() @ w.float().t() + b.float()
     ref = full[:, :inner] * F.gelu(full[:, inner:]) + r.float()
@@ -587,7 +593,7 @@ def test_gemm_folded_layernorm(L, dtype, cfg, shape):
     if N % 32 == 0:
         g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=(bm, bn, 1))
         r = ref.to(DEV)
-        assert_close(g, r[:, 0::2] * F.gelu(r[:, 1::2]), dtype, f"folded LN + GEGLU {cfg}", k=8.0)
+        assert_close(g, geglu_ref(r), dtype, f"folded LN + GEGLU {cfg}", k=8.0)
     with pytest.raises(L.ImhError, match="folded LayerNorm"):
         ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(64, 64, 2))
 
