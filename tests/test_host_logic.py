@@ -156,7 +156,7 @@ def test_header_enums_match_python_constants():
     hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
     vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
     vals.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(IMH_(?:EW|OP|GF)_[A-Z0-9_]+)\s+(\d+)", hdr)})
-    assert len([k for k in vals if k.startswith("IMH_EW_")]) == 11
+    assert len([k for k in vals if k.startswith("IMH_EW_")]) == 12
     for k, v in vals.items():
         py = k[len("IMH_"):]
         if hasattr(lib, py):
@@ -377,7 +377,8 @@ def test_derived_weight_caches_follow_in_place_updates():
             p.copy_(torch.randn(p.shape, generator=g))
     qk0 = _packed_qk(attn, ctx).clone()
     assert _packed_qk(attn, ctx).data_ptr() == _packed_qk(attn, ctx).data_ptr()          # cached while nothing changes
-    w0, b0, s0, c0 = [t.clone() for t in ge.packed_ln(ctx, norm)]
+    w0, b0, s0, c0 = [t.clone() if t is not None else None for t in ge.packed_ln(ctx, norm)]
+    assert b0 is None                    # the Linear's bias rides in the fold's constant term c = W beta + b
     cw0 = conv.packed(ctx).clone()
     key = lambda: (_vkey(attn.to_q.weight, norm.weight, norm.bias), ctx.dtype, str(ctx.device))
     f0 = [t.clone() for t in _cached(attn, "_imh_ln_q", key(), lambda: fold_ln(attn.to_q.weight, norm, ctx))]
