@@ -29,10 +29,18 @@ class DenoiseEngine:
     @torch.no_grad()
     def set_conditioning(self, prompt_embeds, negative_prompt_embeds, pooled, negative_pooled, height, width,
                          guidance_scale=5.0, guidance_rescale=0.0, original_size=None, crops_coords_top_left=(0, 0),
-                         target_size=None):
+                         target_size=None, cfg_role=None):
         """prompt_embeds: [S, 77+T, 2048] (IP tokens already concatenated, ip_adapter.py:321-322).
         original_size / crops_coords_top_left / target_size: SDXL micro-conditioning (custom_pipelines.py:277-293),
-        default (height, width), (0, 0), (height, width)."""
+        default (height, width), (0, 0), (height, width).
+        cfg_role = 0 / 1: this engine computes only the unconditional / the conditional half of the CFG pair (UNet batch S
+        instead of 2S); the halves are exchanged every step by denoise_cfg_split (two ranks share one candidate's denoise:
+        the serial tail of the two-stage PNS schedule)."""
+        if cfg_role not in (None, 0, 1):
+            raise ValueError("cfg_role must be None, 0 (unconditional half) or 1 (conditional half)")
+        if cfg_role != getattr(self, "cfg_role", None):
+            self.plan = None
+        self.cfg_role = cfg_role
         self.do_cfg = guidance_scale > 1.0                                   # custom_pipelines.py:223
         self.guidance = float(guidance_scale)
         if float(guidance_rescale) != getattr(self, "guidance_rescale", 0.0):
@@ -41,10 +49,12 @@ class DenoiseEngine:
         S = prompt_embeds.shape[0]
         osz, tsz = tuple(original_size or (height, width)), tuple(target_size or (height, width))
         ids = torch.tensor([list(osz) + list(crops_coords_top_left) + list(tsz)], dtype=torch.float32).repeat(S, 1)   # :277-293
-        if self.do_cfg:                                                      # :295-298 -- order [uncond | cond]
+        if self.do_cfg and cfg_role is None:                                 # :295-298 -- order [uncond | cond]
             ehs = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
             text = torch.cat([negative_pooled, pooled], 0)
             ids = torch.cat([ids, ids], 0)
+        elif self.do_cfg and cfg_role == 0:
+            ehs, text = negative_prompt_embeds, negative_pooled
         else:
             ehs, text = prompt_embeds, pooled
         ctx = Ctx(self.device, self.dtype)      # fresh context: the K/V caches must outlive pooled buffers
@@ -94,7 +104,7 @@ class DenoiseEngine:
         step counter, activation buffers and plan: lets several PNS candidates be in flight on one GPU (one HIP
         stream each), so that kernels of independent candidates fill the CUs a batch-1 kernel leaves idle."""
         e = DenoiseEngine(self.unet, self.device, self.dtype, self.use_graph)
-        for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx"):
+        for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx", "cfg_role"):
             setattr(e, k, getattr(self, k))
         st = StepState()
         src = self.st
@@ -111,8 +121,29 @@ class DenoiseEngine:
         # the time-embedding rows of every step of this schedule under this conditioning: once here, not five launches per step
         self._temb_ctx = Ctx(self.device, self.dtype)          # (its pool owns the table for the life of the plan)
         self.unet.precompute_temb(self._temb_ctx, st, st.t_table)
+        split = self.do_cfg and getattr(self, "cfg_role", None) is not None
         rec = Ctx(self.device, self.dtype, record=True)
-        out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
+        out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg and not split)
+        if split:
+            # this rank's half of the noise prediction ends the forward plan; the CFG combine + scheduler step + step counter are a
+            # second tiny plan over BOTH halves ([uncond | cond] = the layout the fused step reads), run after the per-step exchange
+            if self.use_graph:
+                rec.capture()
+            self.plan, self.noise_pred = rec, out
+            self.np_full = torch.empty((2,) + tuple(out.shape), dtype=out.dtype, device=self.device)
+            tail = Ctx(self.device, self.dtype, record=True)
+            fac = None
+            if getattr(self, "guidance_rescale", 0.0) > 0.0:
+                fac = tail.new(self.S, dtype=torch.float32)
+                tail.ew(L.EW_CFG_RESCALE, fac, a=self.np_full, i=(self.S, self.H * self.W, 0, 0, 0, 0),
+                        f=(0.0, 0.0, self.guidance, self.guidance_rescale), descr="cfg.rescale")
+            tail.ew(L.EW_CFG_STEP, st.latents, a=self.np_full, w=fac, tab=st.coef_tab, step=st.step,
+                    i=(self.S, self.H * self.W, 0, 1, 0, 0), f=(0.0, 0.0, self.guidance, 0.0), descr="cfg+step")
+            tail.ew(L.EW_STEP_SET, st.step, i=(0, 0, 0, 0, 0, 0), descr="step++")
+            if self.use_graph:
+                tail.capture()
+            self.plan_tail = tail
+            return
         rec.tag = 70
         fac = None
         if self.do_cfg and getattr(self, "guidance_rescale", 0.0) > 0.0:     # rescale_noise_cfg, custom_pipelines.py:351-354
@@ -128,10 +159,33 @@ class DenoiseEngine:
         self.noise_pred = out
 
     @torch.no_grad()
+    def denoise_cfg_split(self, latents, exchange):
+        """One candidate's denoise shared by TWO ranks (engines with cfg_role 0 and 1 on the same conditioning and noise): per step
+        each runs the UNet on its half of the CFG pair, `exchange(mine [S*HW*4...]) -> (uncond, cond)` swaps the halves (pns.
+        pair_exchange: one all_gather of [S, HW, 4] values over xGMI), and both apply the identical combine + scheduler step, so
+        the latents stay bit-equal on the two ranks without further traffic.  The two-stage PNS tail (assets/1.png: the judged-best
+        noise x the full denoise) is then `steps` batch-S forwards deep instead of batch-2S ones."""
+        if getattr(self, "cfg_role", None) is None or not self.do_cfg:
+            raise L.ImhError("denoise_cfg_split needs an engine whose conditioning was set with cfg_role = 0 / 1 and guidance > 1")
+        if self.plan is None:
+            self._record()
+        st = self.st
+        st.latents.copy_(latents.to(self.device, torch.float32) * self.init_noise_sigma)
+        self.eager.ew(L.EW_STEP_SET, st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
+        for _ in range(self.steps):
+            self.plan.replay()
+            un, co = exchange(self.noise_pred)
+            self.np_full[0].copy_(un); self.np_full[1].copy_(co)
+            self.plan_tail.replay()
+        return st.latents
+
+    @torch.no_grad()
     def denoise(self, latents, callback=None, callback_steps=1):
         """latents: [S, 4, H/8, W/8] unit-variance noise (CPU or device).  Returns final fp32 latents
         (output_type='latent' of custom_pipelines.py:365-379).  callback(i, t, latents) every ``callback_steps``
         steps (:359-363) is the only thing that makes the host wait inside the loop."""
+        if getattr(self, "cfg_role", None) is not None and self.do_cfg:
+            raise L.ImhError("this engine holds one half of the CFG pair (cfg_role): use denoise_cfg_split")
         if self.plan is None:
             self._record()
         st = self.st

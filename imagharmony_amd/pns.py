@@ -148,14 +148,49 @@ def two_stage_fns(engine, scheduler, preview_steps=10, final_steps=30, **schedul
     return preview, final
 
 
+def pair_groups():
+    """one process group per (rank r, rank r + 1 mod W) pair, created collectively (every rank calls this once, same order): the
+    communicators of the CFG-split final denoise.  Returns {owner: (group, helper)}; {} at world 1."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    out = {}
+    if world < 2:
+        return out
+    for r in range(world):
+        h = (r + 1) % world
+        out[r] = (dist.new_group(ranks=sorted((r, h))), h)
+    return out
+
+
+def pair_exchange(group, role):
+    """exchange(mine) -> (uncond, cond) for DenoiseEngine.denoise_cfg_split: one all_gather of this rank's half of the noise
+    prediction inside the pair's group (group rank 0 holds the unconditional half).  gloo cannot move device tensors of every dtype:
+    there the halves travel through host memory (tests); RCCL gathers in place over xGMI."""
+    def exchange(mine):
+        if dist.get_backend(group) == "gloo" and mine.device.type != "cpu":
+            halves = [torch.empty(mine.shape, dtype=torch.float32) for _ in range(2)]
+            dist.all_gather(halves, mine.detach().float().cpu(), group=group)
+            return halves[0].to(mine.device, mine.dtype), halves[1].to(mine.device, mine.dtype)
+        halves = [torch.empty_like(mine) for _ in range(2)]
+        dist.all_gather(halves, mine.contiguous(), group=group)
+        return halves[0], halves[1]
+    assert role in (0, 1)
+    return exchange
+
+
 def run_pns(denoise_fn: Callable[[torch.Tensor], torch.Tensor], seeds: Sequence[int], latent_shape,
             scorer: Callable[[torch.Tensor], torch.Tensor] = default_scorer, device="cpu",
-            final_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, batch: int = 1):
+            final_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, batch: int = 1,
+            final_split_fn: Optional[Callable] = None, pairs=None):
     """Each rank runs ``denoise_fn(noise [S,4,h,w]) -> latents [S,4,h,w]`` for its share of ``seeds`` (the preview,
     or the full denoise when ``final_fn`` is None), scores them, and the group agrees on the winner.
     ``batch`` = candidates per denoise call (S <= batch): with N > world seeds a rank stacks its candidates into one
     UNet batch (BASELINE.json configs[4]: 4 per GPU -> UNet batch 8), 1.2-1.3x the images/sec of one at a time on
     MI355X; candidates stay independent, so the scores do not depend on ``batch``.
+
+    ``final_split_fn(noise, exchange, role) -> latents`` + ``pairs`` (pair_groups()): the final denoise of the winner is shared
+    by its owner rank and the next rank -- each computes one half of the CFG pair per step and ``exchange`` swaps them
+    (DenoiseEngine.denoise_cfg_split) -- so the serial tail of the two-stage schedule runs on half-size UNet batches; the other
+    ranks idle at the winner broadcast as before.  Falls back to ``final_fn`` at world 1.
 
     Returns dict(best_seed, best_score, scores [N], latents = the winner's latents on every rank;
     with ``final_fn`` the winner's noise is re-denoised by its owner rank and that result is returned)."""
@@ -185,7 +220,14 @@ def run_pns(denoise_fn: Callable[[torch.Tensor], torch.Tensor], seeds: Sequence[
     best = int(torch.argmax(scores))            # ties -> lowest index: identical on every rank
     owner = best % world
     best_seed = seeds[best]
-    if rank == owner:
+    split = final_split_fn is not None and pairs and world > 1
+    helper = pairs[owner][1] if split else None
+    if split and rank in (owner, helper):
+        group = pairs[owner][0]
+        role = sorted((owner, helper)).index(rank)          # group rank 0 = the unconditional half
+        out = final_split_fn(seed_latents(best_seed, latent_shape), pair_exchange(group, role), role).detach().clone()
+        out = out.to(device=device, dtype=torch.float32).contiguous()
+    elif rank == owner:
         out = local_lat[best_seed]
         if final_fn is not None:
             out = final_fn(seed_latents(best_seed, latent_shape)).detach().clone()

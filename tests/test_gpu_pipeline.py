@@ -80,6 +80,56 @@ def test_denoise_denoising_end_truncates_like_reference():
     assert rel_rms(out, full) > 1e-2
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+def test_denoise_cfg_split_over_two_engines_matches_the_fused_step(dtype, tol):
+    """the two-stage PNS tail shared by two ranks (DenoiseEngine cfg_role 0 / 1 + denoise_cfg_split): each engine runs the UNet on
+    ITS half of the CFG pair, the halves are exchanged every step, both apply the same combine + DDIM step.  Here the two "ranks"
+    are two engines on one GPU stepped in lockstep (the exchange is a local swap; over RCCL it is pns.pair_exchange's all_gather,
+    covered under gloo by tests/test_pns_gloo.py): the latents of both stay bit-equal to each other and match the fused engine and
+    the CPU oracle loop (custom_pipelines.py:324-363) within the trajectory bound"""
+    from imagharmony_amd import lib as L
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.denoise import DenoiseEngine
+    from oracle.pipeline import denoise as oracle_denoise
+    from oracle.schedulers import DDIMScheduler as OracleDDIM
+    steps, hw = 3, 32
+    ou, hu, ocfg = build_pair(DEV, dtype)
+    lat = det_randn((1, 4, hw, hw), 3)
+    pe, ne = det_randn((1, 81, ocfg.cross_attention_dim), 4), det_randn((1, 81, ocfg.cross_attention_dim), 5)
+    po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
+    ref = oracle_denoise(ou, OracleDDIM(), lat, pe, ne, po, no, hw * 8, hw * 8, num_inference_steps=steps, guidance_scale=5.0)
+    engs = []
+    for role in (None, 0, 1):
+        e = DenoiseEngine(hu, DEV, dtype, use_graph=True)
+        e.set_conditioning(pe.to(DEV), ne.to(DEV), po.to(DEV), no.to(DEV), hw * 8, hw * 8, guidance_scale=5.0, cfg_role=role)
+        e.set_schedule(hs.DDIMScheduler(), steps)
+        engs.append(e)
+    fused = engs[0].denoise(lat).float().cpu().clone()
+    with pytest.raises(L.ImhError, match="denoise_cfg_split"):
+        engs[1].denoise(lat)
+    # lockstep emulation of the two ranks: forward halves, swap, identical tails
+    a, b = engs[1], engs[2]
+    for e in (a, b):
+        if e.plan is None:
+            e._record()
+        e.st.latents.copy_(lat.to(DEV, torch.float32) * e.init_noise_sigma)
+        e.eager.ew(L.EW_STEP_SET, e.st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
+    assert a.noise_pred.shape[0] == 1                     # UNet batch S, not 2S
+    for _ in range(steps):
+        a.plan.replay(); b.plan.replay()
+        for e in (a, b):
+            e.np_full[0].copy_(a.noise_pred); e.np_full[1].copy_(b.noise_pred)
+            e.plan_tail.replay()
+        assert torch.equal(a.st.latents, b.st.latents)
+    out = a.st.latents.float().cpu()
+    r_ref, r_fused = rel_rms(out, ref), rel_rms(out, fused)
+    print(f"CFG-split denoise {dtype}: rel-rms vs oracle {r_ref:.3e}, vs the fused engine {r_fused:.3e}")
+    assert torch.isfinite(out).all() and r_ref < tol and r_fused < tol
+    # the blocking entry point refuses an engine that holds the whole pair
+    with pytest.raises(L.ImhError, match="cfg_role"):
+        engs[0].denoise_cfg_split(lat, lambda m: (m, m))
+
+
 def test_denoise_is_deterministic_and_replayable():
     a, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
     b, _ = denoise_pair(DEV, torch.bfloat16, steps=2)

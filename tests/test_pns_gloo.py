@@ -1,6 +1,8 @@
-"""CPU, world_size 2 over gloo: the PNS sharding / gather / winner-broadcast logic (imagharmony_amd.pns).
+"""CPU, world_size 2 / 4 / 8 over gloo: the PNS sharding / gather / winner-broadcast logic (imagharmony_amd.pns).
 The denoiser is a deterministic stand-in (the HIP engine needs a GPU); what is tested is the N>1 path:
-seed sharding, score all_gather order, identical winner on every rank, latent broadcast from the owner."""
+seed sharding (also N < W: idle ranks; N = 32 stacked 4 per call), score all_gather order, identical winner on every rank, latent
+broadcast from the owner, the two-stage final denoise on the owner, and the CFG-split final denoise shared by the owner and the
+next rank (one all_gather of the two noise-prediction halves per step inside the pair's group)."""
 import os
 import socket
 
@@ -94,3 +96,73 @@ def test_shard_and_seed_noise():
     assert torch.equal(a, b) and not torch.equal(a, pns.seed_latents(6, (1, 4, 8, 8)))
     s = pns.default_scorer(torch.randn(3, 4, 8, 8))
     assert s.shape == (3,)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worlds 4 and 8; N < W; N = 32 stacked; CFG-split final denoise
+STEPS, GUIDE = 6, 5.0
+
+
+def _half(lat, role):
+    """stand-in for one half of the CFG pair's UNet forward (role 0 unconditional, 1 conditional)"""
+    return lat * (0.1 if role == 0 else 0.2) + (0.0 if role == 0 else 0.3) * lat.mean(dim=(1, 2, 3), keepdim=True)
+
+
+def _fused_final(noise):
+    lat = noise.clone()
+    for _ in range(STEPS):
+        un, co = _half(lat, 0), _half(lat, 1)
+        lat = lat - 0.05 * (un + GUIDE * (co - un))
+    return lat
+
+
+def _split_final(noise, exchange, role):
+    lat = noise.clone()
+    for _ in range(STEPS):
+        un, co = exchange(_half(lat, role))
+        lat = lat - 0.05 * (un + GUIDE * (co - un))
+    return lat
+
+
+def _worker_n(rank, world, port, seeds, q, batch, split):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = pns.pair_groups() if split else None
+        calls = []
+
+        def preview(noise):
+            calls.append(noise.shape[0])
+            return _fake_denoise(noise)
+        r = pns.run_pns(preview, seeds, (1, 4, 8, 8), final_fn=_fused_final, batch=batch,
+                        final_split_fn=_split_final if split else None, pairs=pairs)
+        q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].clone(), r["owner"], calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_seeds,batch,split", [(4, 3, 1, False), (4, 32, 4, False), (4, 6, 1, True), (8, 5, 1, True), (8, 32, 4, False), (2, 4, 1, True)])
+def test_pns_wider_worlds_idle_ranks_stacking_and_cfg_split_final(world, n_seeds, batch, split):
+    seeds = [(7 * i + 3) % 101 for i in range(n_seeds)]
+    single = pns.run_pns(_fake_denoise, seeds, (1, 4, 8, 8), final_fn=_fused_final)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, seeds, q, batch, split)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    best_idx = seeds.index(single["best_seed"])
+    for rank, best, scores, lat, owner, calls in res:
+        assert best == single["best_seed"] and owner == best_idx % world
+        assert torch.allclose(torch.tensor(scores), single["scores"], atol=1e-6)
+        # the split final (two ranks, halves exchanged every step) reproduces the fused one: same arithmetic on the same values
+        assert torch.allclose(lat, single["latents"], atol=1e-5), (rank, (lat - single["latents"]).abs().max())
+        mine = pns.shard(seeds, rank, world)
+        assert sum(calls) == len(mine) and (not mine or max(calls) <= batch)         # idle ranks (N < W) denoise nothing
+        if n_seeds < world and rank >= n_seeds:
+            assert calls == []
