@@ -43,6 +43,12 @@ CONFIGS = collections.OrderedDict([
     ("gn_fused_w8", dict(gn_fuse=True, halo=1)),      # imh_debug_set key 5: 1 = the eight-wave conv form for the fused launches too
     ("halo_w12", dict(gn_fuse=True, halo=2)),         # 2 = four halo waves for every LDS-halo conv
     # self-attention projections: the two-problem launch of round 3 vs ONE wave-specialised [Q|K|V] launch (at both widths / at C = 1280 only)
+    # round-4 tile checks (in situ): [Q|K|V] at C = 640 on 128-row tiles; conv_shortcut over the 960-channel concat on the
+    # wave-specialised 128 x 160; the fused 64 x 64 convolutions on 320-cout tiles
+    ("qkv640_24128", dict(tuning={"8192,1920,640,0,1": [24128, 160, 1]})),
+    ("sc960_24128", dict(tuning={"32768,320,960,0": [24128, 160, 1], "32768,320,640,0": [24128, 160, 1]})),
+    ("conv64_320", dict(tuning={f"8192,640,{k},1": [7128, 320, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
+    ("conv128_7128", dict(tuning={f"32768,320,{k},1": [7128, 320, 1] for k in (2880, 5760, 8640)})),
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
     ("qkv_one_1280", dict(qkv_one=True, qkv_widths=(1280,))),
@@ -114,7 +120,17 @@ def main():
         for (tag, kind, descr, fl, by_, *rest), t in zip(rec.tags, res[n]["per_op"]):
             d = by.setdefault(descr, dict(n=0, ms=0.0, gflop=0.0))
             d["n"] += 1; d["ms"] += t; d["gflop"] += fl / 1e9
-        out[n] = dict(cfg=c, rel_rms_vs_first=res[n]["rel_rms_vs_first"], n_ops=len(rec.tags), sum_of_ops_ms=sum(res[n]["per_op"]),
+        shp = collections.OrderedDict()          # GEMM / conv launches by (op, shape, variant): the floor model's input (tools/floor_model.py)
+        for (tag, kind, descr, fl, by_, *rest), t in zip(rec.tags, res[n]["per_op"]):
+            shape, epi = (rest + [None, None])[:2]
+            if kind != L.OP_GEMM or shape is None or not epi or "cfg" not in epi:
+                continue
+            k2 = (descr, tuple(shape[:4]), tuple(epi["cfg"]))
+            d2 = shp.setdefault(k2, dict(n=0, ms=0.0))
+            d2["n"] += 1; d2["ms"] += t
+        by_shape = [dict(op=k2[0], M=k2[1][0], N=k2[1][1], K=k2[1][2], conv=k2[1][3], cfg=list(k2[2]), n=d2["n"], us_each=1e3 * d2["ms"] / d2["n"])
+                    for k2, d2 in shp.items()]
+        out[n] = dict(cfg=c, rel_rms_vs_first=res[n]["rel_rms_vs_first"], n_ops=len(rec.tags), sum_of_ops_ms=sum(res[n]["per_op"]), by_shape=by_shape,
                       wall_ms_median=statistics.median(res[n]["wall_ms"]), wall_ms_min=min(res[n]["wall_ms"]), wall_ms=res[n]["wall_ms"],
                       by_descr={k: dict(n=d["n"], ms=round(d["ms"], 4), us_each=round(1e3 * d["ms"] / d["n"], 2),
                                         tflops=round(d["gflop"] / d["ms"], 1) if d["ms"] > 0 else 0) for k, d in
