@@ -344,7 +344,7 @@ def pns_two_stage(eng, pipe, device, lat_shape, N=8, preview_steps=10, final_ste
             "ceiling_speedup_8_ranks": (t2 - t0) / ((t1 - t0) / N + (t2 - t1)), "outputs_finite": bool(torch.isfinite(out).all().item()),
             "note": "one rank runs all N previews back to back, then the final denoise; at 8 ranks the previews shard 8 ways and the "
                     "final denoise stays on the owner rank (pns.run_pns) unless its CFG halves are split over two ranks "
-                    "(pns.cfg_split_denoise)"}
+                    "(DenoiseEngine.denoise_cfg_split through pns.run_pns(final_split_fn=...): measured no faster, DESIGN.md 7)"}
 
 
 def _self_launch(n, script=None, argv=None):
@@ -497,7 +497,7 @@ def main():
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
         try:
-            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
+            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
                                                                           "r01_pmc_hbm_traffic_final.json")) if os.path.exists(q))
             traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
             traffic_src = f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command with --denoise-steps 4)"

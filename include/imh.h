@@ -366,7 +366,10 @@ int imh_plan_get_tag(const imh_plan* p, int index);
 int imh_plan_get_kind(const imh_plan* p, int index);
 
 /* tuning / debugging knobs -- key 0: retired (attention workgroups are always 4 waves; accepted and ignored);
- * key 2: XCD tile placement (0 auto, 1 legacy row-major, 2..5 force the (8,1) (4,2) (2,4) (1,8) partition) */
+ * key 2: XCD tile placement (0 auto, 1 legacy row-major, 2..5 force the (8,1) (4,2) (2,4) (1,8) partition);
+ * keys 3 / 4: cross- / self-attention kernel selection, key 5: LDS-halo conv form (0 auto, 1 eight waves, 2 halo waves),
+ * A/B and test use only: the values are process-wide plain ints read at launch time, not meant to change while another
+ * thread is launching */
 int imh_debug_set(int key, int value);
 
 const char* imh_last_error(void);

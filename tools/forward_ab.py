@@ -49,9 +49,19 @@ CONFIGS = collections.OrderedDict([
     ("sc960_24128", dict(tuning={"32768,320,960,0": [24128, 160, 1], "32768,320,640,0": [24128, 160, 1]})),
     ("conv64_320", dict(tuning={f"8192,640,{k},1": [7128, 320, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("conv128_7128", dict(tuning={f"32768,320,{k},1": [7128, 320, 1] for k in (2880, 5760, 8640)})),
+    # the 32 x 32 ResBlock convolutions on the 4 x 16-patch LDS-halo form (GroupNorm + SiLU + concat fused) instead of the
+    # wave-specialised 64 x 160 implicit GEMM behind a table + apply pass
+    ("conv32_7564", dict(tuning={f"2048,1280,{k},1": [7564, 160, 1] for k in (5760, 11520, 17280, 23040)})),
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
     ("qkv_one_1280", dict(qkv_one=True, qkv_widths=(1280,))),
+    # the round-3 launch structure as far as it can still be selected: [Q|K] + V^T two-problem launch, GroupNorm as table + apply
+    # passes in front of every conv (the erf-GELU polynomial and the statistics-only LayerNorm hand-over cannot be switched back)
+    ("round3_like", dict(qkv_one=False, gn_fuse=False)),
+    # (measured with this tool and removed from the tree again, results kept: the [Q|K|V] column tiles dealt to the XCDs by head
+    # group so that Q, K, V of a head are written on the XCD that reads them -- profiles/r04_forward_ab_qkv_xcd_affinity.json, no
+    # change; an L2 warm-up touch of the head's K / V^T lines at entry of the attention kernels --
+    # profiles/r04_forward_ab_attn_kv_warmup.json, +1.8 / +0.8 us per launch)
     ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)),
 ])
 
