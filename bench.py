@@ -517,6 +517,10 @@ def main():
                                        "post-processing tail (custom_pipelines.py:365-386) is NOT in `value` -- its time is "
                                        "reported under vae_decode",
                        "ms_per_unet_forward": dt / a.steps / a.denoise_steps * 1e3,
+                       "xcd_cells": {"chosen": eng.xcd_cells, "ms_per_step_when_picked": getattr(eng, "xcd_times_ms", None),
+                                     "note": "XCD cell shape of the GEMM / conv tile grids, measured once when the plan is recorded "
+                                             "(DenoiseEngine._pick_xcd_cells, outside the timed region): 0 = byte-count model, "
+                                             "3 = 4 x 2, 2 = 8 x 1 cells over M x N; bit-identical results, box-dependent speed"},
                        "tflop_per_unet_forward": tot_fl / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes per launch",

@@ -42,7 +42,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;
     p.rows_per_batch = a->rows_per_batch; p.splits = a->splits; p.flags = a->flags;
     p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.stride = a->stride; p.up = a->up;
-    p.px = p.py = 1; p.tmx = p.tny = 0;
+    p.px = p.py = 1; p.tmx = p.tny = 0; p.xcd = a->xcd;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
     return p;
 }

@@ -42,7 +42,8 @@ inline void xcd_partition(GemmParams& p, int bm, int bn, int* grid) {
         const double cost = ((double)c[1] * p.M + (double)c[0] * p.N) * waste * waste;
         if (cost < best) { best = cost; bpx = c[0]; bpy = c[1]; }
     }
-    if (g_xcd_mode >= 2 && g_xcd_mode <= 5) { bpx = cand[g_xcd_mode - 2][0]; bpy = cand[g_xcd_mode - 2][1]; }
+    const int forced = g_xcd_mode ? g_xcd_mode : p.xcd;          // the debug knob wins over the launch's own request
+    if (forced >= 2 && forced <= 5) { bpx = cand[forced - 2][0]; bpy = cand[forced - 2][1]; }
     p.px = bpx; p.py = bpy;
     p.tmx = (tm + bpx - 1) / bpx;
     p.tny = (tn + bpy - 1) / bpy;

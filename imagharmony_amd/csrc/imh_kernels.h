@@ -47,6 +47,7 @@ struct GemmParams {
     int H, Wd, Cin, Ho, Wo, stride, up;
     // XCD-aware tile placement (set by the launchers): the 8 XCDs form a px x py grid over the tile space
     int px, py, tmx, tny;
+    int xcd;               // requested cell shape (imh_gemm_args.xcd): 0 = cost model, 2 .. 5 = (8,1) (4,2) (2,4) (1,8)
     const void* pf_ptr;    // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
 };

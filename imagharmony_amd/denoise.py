@@ -6,6 +6,8 @@ One denoise step = [UNet forward on the CFG-duplicated latent] + [CFG combine + 
 scale and the per-step IP-scale gate (control_guidance_start/end, custom_pipelines.py:326-329) are
 device tables indexed by a device-resident step counter.
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -24,6 +26,10 @@ class DenoiseEngine:
         self.plan = None
         self.key = None
         self.noise_pred = None
+        # XCD cell shapes tried when the plan is first recorded (_pick_xcd_cells): the byte-count model, 4 x 2 and 8 x 1 cells; the
+        # choice sticks for the life of the engine (IMH_XCD_AUTOTUNE=0: model only)
+        self.xcd_candidates = (0, 3, 2) if os.environ.get("IMH_XCD_AUTOTUNE", "1") != "0" else (0,)
+        self.xcd_cells = None
 
     # -- conditioning (once per image / per PNS run; shared by every candidate seed) --
     @torch.no_grad()
@@ -104,7 +110,8 @@ class DenoiseEngine:
         step counter, activation buffers and plan: lets several PNS candidates be in flight on one GPU (one HIP
         stream each), so that kernels of independent candidates fill the CUs a batch-1 kernel leaves idle."""
         e = DenoiseEngine(self.unet, self.device, self.dtype, self.use_graph)
-        for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx", "cfg_role"):
+        for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx", "cfg_role",
+                  "xcd_candidates", "xcd_cells"):
             setattr(e, k, getattr(self, k))
         st = StepState()
         src = self.st
@@ -122,7 +129,10 @@ class DenoiseEngine:
         self._temb_ctx = Ctx(self.device, self.dtype)          # (its pool owns the table for the life of the plan)
         self.unet.precompute_temb(self._temb_ctx, st, st.t_table)
         split = self.do_cfg and getattr(self, "cfg_role", None) is not None
+        if not split and self.use_graph and len(self.xcd_candidates) > 1 and self.xcd_cells is None:
+            self.xcd_cells = self._pick_xcd_cells()
         rec = Ctx(self.device, self.dtype, record=True)
+        rec.xcd_cells = self.xcd_cells or 0
         out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg and not split)
         if split:
             # this rank's half of the noise prediction ends the forward plan; the CFG combine + scheduler step + step counter are a
@@ -157,6 +167,32 @@ class DenoiseEngine:
             rec.capture()
         self.plan = rec
         self.noise_pred = out
+
+    def _pick_xcd_cells(self):
+        """Which XCD cell shape this box prefers for the GEMM / conv launches of the forward (imh_gemm_args.xcd): the byte-count model
+        (0), or 4 x 2 (3) / 8 x 1 (2) cells over M x N everywhere.  Bit-identical results either way; the faster one differs from box to box
+        (fresh MI355X boxes, same build: the model is 0.3 ms per forward ahead on a 19.9-ms box and 0.4 ms behind on 21.5-ms boxes,
+        profiles/r04_forward_ab_xcd_cells*.json), so it is measured once per engine: each candidate's forward is recorded,
+        captured and replayed a few times; the winner's plan is then recorded for real by _record()."""
+        st = self.st
+        times = {}
+        for cells in self.xcd_candidates:
+            rec = Ctx(self.device, self.dtype, record=True)
+            rec.xcd_cells = cells
+            self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
+            rec.capture()
+            best = None
+            for i in range(4):
+                self.eager.ew(L.EW_STEP_SET, st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); rec.replay(); e1.record()
+                torch.cuda.synchronize(self.device)
+                if i:                                      # the first replay is the warm-up
+                    best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
+            times[cells] = best
+            del rec
+        self.xcd_times_ms = times
+        return min(times, key=times.get)
 
     @torch.no_grad()
     def denoise_cfg_split(self, latents, exchange):

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),
                 ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("stride", _i32), ("up", _i32),
-                ("dtype", _i32), ("conv", _i32), ("bm", _i32), ("bn", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32)]
+                ("dtype", _i32), ("conv", _i32), ("bm", _i32), ("bn", _i32), ("pf_ptr", _vp), ("pf_bytes", C.c_uint32), ("xcd", _i32)]
 
 
 class AttnArgs(C.Structure):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 6
+#define IMH_ABI_VERSION 7
 
 enum imh_status {
     IMH_OK = 0,
@@ -149,6 +149,10 @@ typedef struct imh_gemm_args {
     /* cache hint: the NEXT launch's weight matrix; exiting workgroups touch it (HBM -> L2 / Infinity Cache) */
     const void* pf_ptr;
     uint32_t pf_bytes;
+    /* how the tile grid is dealt to the eight XCDs (workgroup w runs on XCD w % 8; each XCD takes one cell of an M x N grid of
+     * cells): 0 = the byte-count model picks the shape, 2 / 3 / 4 / 5 = 8 x 1 / 4 x 2 / 2 x 4 / 1 x 8 cells.  Placement only:
+     * results are bit-identical.  Which shape is faster depends on the box, so the host measures. */
+    int32_t xcd;
 } imh_gemm_args;
 
 int imh_gemm(const imh_gemm_args* a, void* stream);

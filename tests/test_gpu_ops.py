@@ -79,6 +79,13 @@ def test_gemm_big_tile_variants(L, dtype, cfg):
         assert_close(y0, ref, dtype, f"gemm {cfg} {(M, N, K)}")
         for _ in range(3):
             assert torch.equal(ctx.gemm(x, w, bias=b, residual=r, cfg=cfg), y0), f"{cfg} {(M, N, K)} not repeatable"
+        # the XCD cell shape of the tile grid (imh_gemm_args.xcd) is placement only: every tile is computed exactly once whatever the shape
+        try:
+            for cells in (2, 3, 4, 5):
+                ctx.xcd_cells = cells
+                assert torch.equal(ctx.gemm(x, w, bias=b, residual=r, cfg=cfg), y0), f"{cfg} {(M, N, K)} xcd cells {cells}"
+        finally:
+            ctx.xcd_cells = 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

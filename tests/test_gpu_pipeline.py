@@ -130,6 +130,33 @@ def test_denoise_cfg_split_over_two_engines_matches_the_fused_step(dtype, tol):
         engs[0].denoise_cfg_split(lat, lambda m: (m, m))
 
 
+def test_engine_picks_an_xcd_cell_shape_and_every_shape_gives_the_same_bits():
+    """DenoiseEngine measures, when it first records its plan, which XCD cell shape of the GEMM / conv tile grids this box prefers
+    (imh_gemm_args.xcd through Ctx.xcd_cells).  Placement only: every shape, the engine's pick included, denoises to the
+    same bits (custom_pipelines.py:324-363 is the loop being run)"""
+    from imagharmony_amd import schedulers as hs
+    from imagharmony_amd.denoise import DenoiseEngine
+    steps, hw = 2, 32
+    ou, hu, ocfg = build_pair(DEV, torch.bfloat16)
+    lat = det_randn((1, 4, hw, hw), 3)
+    pe, ne = det_randn((1, 81, ocfg.cross_attention_dim), 4), det_randn((1, 81, ocfg.cross_attention_dim), 5)
+    po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
+    outs = {}
+    for cells in (None, 0, 2, 3, 4, 5):
+        e = DenoiseEngine(hu, DEV, torch.bfloat16, use_graph=True)
+        if cells is not None:
+            e.xcd_candidates, e.xcd_cells = (cells,), cells
+        e.set_conditioning(pe.to(DEV), ne.to(DEV), po.to(DEV), no.to(DEV), hw * 8, hw * 8, guidance_scale=5.0)
+        e.set_schedule(hs.DDIMScheduler(), steps)
+        outs[cells] = e.denoise(lat).float().cpu().clone()
+        if cells is None:
+            assert e.xcd_cells in e.xcd_candidates and set(e.xcd_times_ms) == set(e.xcd_candidates)
+            assert all(t > 0 for t in e.xcd_times_ms.values())
+            assert e.fork().xcd_cells == e.xcd_cells           # in-flight candidates reuse the pick
+    for cells, o in outs.items():
+        assert torch.equal(o, outs[0]), f"xcd cells {cells}"
+
+
 def test_denoise_is_deterministic_and_replayable():
     a, _ = denoise_pair(DEV, torch.bfloat16, steps=2)
     b, _ = denoise_pair(DEV, torch.bfloat16, steps=2)

@@ -64,6 +64,10 @@ CONFIGS = collections.OrderedDict([
     # group so that Q, K, V of a head are written on the XCD that reads them -- profiles/r04_forward_ab_qkv_xcd_affinity.json, no
     # change; an L2 warm-up touch of the head's K / V^T lines at entry of the attention kernels --
     # profiles/r04_forward_ab_attn_kv_warmup.json, +1.8 / +0.8 us per launch)
+    # XCD cell shape forced for EVERY GEMM / conv launch (imh_debug_set key 2): (8,1) (4,2) (2,4) (1,8) = M x N cells; read per op
+    ("base_again", dict()),                            # position control: the same configuration twice in one interleaved round
+    ("xcd81", dict(xcd=2)), ("xcd42", dict(xcd=3)), ("xcd24", dict(xcd=4)), ("xcd18", dict(xcd=5)),
+    ("xcd_m2", dict(xcd=6)), ("xcd_m3", dict(xcd=7)),   # the cost model restricted to (8,1) (4,2) / to (8,1) (4,2) (2,4)
     ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)),
 ])
 
