@@ -72,7 +72,8 @@ class Ctx:
         self._ws = None
         self.tuning = _load_tuning()
         # XCD cell shape every GEMM / implicit-GEMM launch of this context asks for (imh_gemm_args.xcd: 0 = the byte-count model,
-        # 2 .. 5 = 8 x 1 / 4 x 2 / 2 x 4 / 1 x 8 cells over M x N); placement only -- DenoiseEngine measures which one this box prefers
+        # 2 .. 5 = 8 x 1 / 4 x 2 / 2 x 4 / 1 x 8 cells over M x N; + 10: the GEGLU launches (N = 8 C) keep the model's N-major
+        # choice); placement only -- DenoiseEngine measures which one this box prefers
         self.xcd_cells = 0
         self.captured = False
         self._ops = []          # recorded (kind, ctypes args, cold tensors) for the weight-prefetch pass
@@ -283,7 +284,7 @@ class Ctx:
         a.ldra = ldra
         a.rows_per_batch = rows_per_batch
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, flags, self.dt, 0, bm, bn
-        a.xcd = self.xcd_cells
+        a.xcd = self.xcd_cells % 10 if not (self.xcd_cells >= 10 and flags & L.GF_GEGLU) else 0
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
         st = None
@@ -415,7 +416,7 @@ class Ctx:
         a.ldra = ldra
         a.rows_per_batch = Ho * Wo
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, 0, self.dt, 1, bm, bn
-        a.xcd = self.xcd_cells
+        a.xcd = self.xcd_cells % 10
         a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
         if x2 is not None:
             a.X2, a.Cin1 = x2.data_ptr(), C1

@@ -26,9 +26,10 @@ class DenoiseEngine:
         self.plan = None
         self.key = None
         self.noise_pred = None
-        # XCD cell shapes tried when the plan is first recorded (_pick_xcd_cells): the byte-count model, 4 x 2 and 8 x 1 cells; the
-        # choice sticks for the life of the engine (IMH_XCD_AUTOTUNE=0: model only)
-        self.xcd_candidates = (0, 3, 2) if os.environ.get("IMH_XCD_AUTOTUNE", "1") != "0" else (0,)
+        # XCD cell shapes tried when the plan is first recorded (_pick_xcd_cells): the byte-count model, 4 x 2 and 8 x 1 cells, and
+        # 4 x 2 with the GEGLU launches left to the model (13); the choice sticks for the life of the engine
+        # (IMH_XCD_AUTOTUNE=0: model only)
+        self.xcd_candidates = (0, 3, 2, 13) if os.environ.get("IMH_XCD_AUTOTUNE", "1") != "0" else (0,)
         self.xcd_cells = None
 
     # -- conditioning (once per image / per PNS run; shared by every candidate seed) --

@@ -142,7 +142,7 @@ def test_engine_picks_an_xcd_cell_shape_and_every_shape_gives_the_same_bits():
     pe, ne = det_randn((1, 81, ocfg.cross_attention_dim), 4), det_randn((1, 81, ocfg.cross_attention_dim), 5)
     po, no = det_randn((1, ocfg.pooled_dim), 6), det_randn((1, ocfg.pooled_dim), 7)
     outs = {}
-    for cells in (None, 0, 2, 3, 4, 5):
+    for cells in (None, 0, 2, 3, 4, 5, 13):
         e = DenoiseEngine(hu, DEV, torch.bfloat16, use_graph=True)
         if cells is not None:
             e.xcd_candidates, e.xcd_cells = (cells,), cells

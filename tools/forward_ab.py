@@ -65,6 +65,7 @@ CONFIGS = collections.OrderedDict([
     # change; an L2 warm-up touch of the head's K / V^T lines at entry of the attention kernels --
     # profiles/r04_forward_ab_attn_kv_warmup.json, +1.8 / +0.8 us per launch)
     # XCD cell shape forced for EVERY GEMM / conv launch (imh_debug_set key 2): (8,1) (4,2) (2,4) (1,8) = M x N cells; read per op
+    ("cells13", dict(cells=13)), ("cells3", dict(cells=3)),      # Ctx.xcd_cells (the per-launch request, as DenoiseEngine picks it)
     ("base_again", dict()),                            # position control: the same configuration twice in one interleaved round
     ("xcd81", dict(xcd=2)), ("xcd42", dict(xcd=3)), ("xcd24", dict(xcd=4)), ("xcd18", dict(xcd=5)),
     ("xcd_m2", dict(xcd=6)), ("xcd_m3", dict(xcd=7)),   # the cost model restricted to (8,1) (4,2) / to (8,1) (4,2) (2,4)
@@ -100,7 +101,7 @@ def main():
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
-        rec, out, st = record(u, dtype, 128, S=a.stacked, tuning=tun)
+        rec, out, st = record(u, dtype, 128, S=a.stacked, tuning=tun, cells=int(c.get("cells", 0)))
         rec.run()
         torch.cuda.synchronize()
         plans[n] = (rec, c)

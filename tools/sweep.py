@@ -37,7 +37,7 @@ def build_unet(dtype, num_tokens=4):
     return u
 
 
-def record(u, dtype, lat, S=1, T=4, tuning=None):
+def record(u, dtype, lat, S=1, T=4, tuning=None, cells=0):
     pre = Ctx(DEV, dtype)
     g = torch.Generator(device="cpu").manual_seed(7)
     ehs = torch.randn(2 * S, 77 + T, 2048, generator=g).to(DEV, dtype)
@@ -49,6 +49,7 @@ def record(u, dtype, lat, S=1, T=4, tuning=None):
     rec = Ctx(DEV, dtype, record=True)
     if tuning is not None:
         rec.tuning = tuning
+    rec.xcd_cells = cells
     out = u.emit_forward(rec, st, S, lat, lat, cfg_dup=True)
     return rec, out, st
 
