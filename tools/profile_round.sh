@@ -10,10 +10,13 @@ mkdir -p $out
 timeout 600 python bench.py --steps 5 --warmup 2 > $out/${tag}_bench_n1.json 2> $out/${tag}_bench_n1.err; echo "bench rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -o k -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1 --stacked 1 > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err; echo "trace rc=$?"
 python tools/rocpd_summary.py $(find $out/${tag}_kt -name "*results.db" | head -1) $out/${tag}_bench_kernel_stats.md "${tag}: python bench.py --steps 3 --warmup 1 under rocprofv3 --kernel-trace --stats" > /dev/null
+# (the PMC passes run the byte-count model's XCD cells only: the engine's pick would put three more candidate plans in the counters)
+export IMH_XCD_AUTOTUNE=0
 B="python bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --in-flight 1 --stacked 1"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $out/${tag}_pf -o f -- $B > /dev/null 2>&1; echo "fetch rc=$?"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $out/${tag}_pw -o w -- $B > /dev/null 2>&1; echo "write rc=$?"
 python tools/pmc_summary.py $(find $out/${tag}_pf -name "*results.db" | head -1) $(find $out/${tag}_pw -name "*results.db" | head -1) $out/${tag}_pmc_hbm_traffic.json $out/${tag}_pmc_hbm_traffic.md
+unset IMH_XCD_AUTOTUNE
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS -d $out/${tag}_s1 -o s -- python tools/pmc_gemm.py > /dev/null 2>&1; echo "sq1 rc=$?"
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d $out/${tag}_s2 -o s -- python tools/pmc_gemm.py > /dev/null 2>&1; echo "sq2 rc=$?"
 python tools/pmc_sq_summary.py $(find $out/${tag}_s1 -name "*results.db" | head -1) $(find $out/${tag}_s2 -name "*results.db" | head -1) > $out/${tag}_pmc_sq_gemm_attn.md
