@@ -318,6 +318,39 @@ def box_calibration(device, dtype, reps=20):
                     "scales this box against it"}
 
 
+class ClockSampler:
+    """shader clock and socket power while the timed steps run, sampled from the host (rocm-smi reads sysfs; nothing is launched on the
+    GPU): the part sustains 1.8-2.1 GHz under these kernels, not the 2.4 GHz its MFMA peak is quoted at (profiles/r04_clocks_under_load.txt)"""
+    def __init__(self, period=1.0):
+        import re, subprocess, threading
+        self.rows, self._stop, self._re, self._sp = [], False, re, subprocess
+        self.period = period
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while not self._stop:
+            try:
+                t = self._sp.run("rocm-smi --showpower --showclocks", shell=True, capture_output=True, text=True, timeout=5).stdout
+                m1 = self._re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", t)
+                m2 = self._re.search(r"Package Power \(W\): ([\d.]+)", t)
+                if m1 and m2:
+                    self.rows.append((int(m1.group(1)), float(m2.group(1))))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def stop(self):
+        self._stop = True
+        self.th.join(timeout=10)
+        rows = [r for r in self.rows if r[0] > 500]              # (a sample that caught the idle state between steps is not "under load")
+        if not rows:
+            return None
+        return {"sclk_mhz": sum(r[0] for r in rows) / len(rows), "watts": sum(r[1] for r in rows) / len(rows), "samples": len(rows),
+                "mfma_peak_at_this_clock_tflops": 2500.0 * (sum(r[0] for r in rows) / len(rows)) / 2400.0,
+                "note": "rocm-smi sampled from the host during the timed steps; `roofline.peak` stays the 2.4 GHz figure"}
+
+
 def pns_two_stage(eng, pipe, device, lat_shape, N=8, preview_steps=10, final_steps=30):
     """the two-stage schedule of assets/1.png / README.md:27 on ONE rank, end to end: N candidate seeds x a `preview_steps` denoise,
     the judge, then the judged-best noise x the full `final_steps` denoise -- so that the serial tail of the scheme is a number
@@ -450,12 +483,14 @@ def main():
     for i in range(a.warmup):
         eng.denoise(noises[i])
     barrier()
+    clk = ClockSampler() if rank == 0 else None              # host thread reading rocm-smi (sysfs): shader clock / power under load
     t0 = time.perf_counter()
     for i in range(a.warmup, a.warmup + a.steps):
         out = eng.denoise(noises[i])
         scores.append(pns.default_scorer(out))               # tiny; the PNS judge input
     barrier()
     dt = time.perf_counter() - t0
+    clocks = clk.stop() if clk else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -517,6 +552,7 @@ def main():
                                        "post-processing tail (custom_pipelines.py:365-386) is NOT in `value` -- its time is "
                                        "reported under vae_decode",
                        "ms_per_unet_forward": dt / a.steps / a.denoise_steps * 1e3,
+                       "clocks_under_load": clocks,
                        "xcd_cells": {"chosen": eng.xcd_cells, "ms_per_step_when_picked": getattr(eng, "xcd_times_ms", None),
                                      "note": "XCD cell shape of the GEMM / conv tile grids, measured once when the plan is recorded "
                                              "(DenoiseEngine._pick_xcd_cells, outside the timed region): 0 = byte-count model, "

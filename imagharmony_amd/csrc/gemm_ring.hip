@@ -404,6 +404,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 #ifndef WS_ABL
 #define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
 #endif
+// WS_TIMING (tools/ws_phase_probe.py only): cycle counter at the segment boundaries of the K loop; consumer wave 0 and producer wave 0
+// of workgroup 0 write their per-segment totals to p.pf_ptr instead of prefetching --
+//   consumer: [fragment reads + MFMAs] [s_waitcnt lgkmcnt(0)] [s_barrier]     producer: [LDS-DMA issue] [s_waitcnt vmcnt] [s_barrier]
+#ifndef WS_TIMING
+#define WS_TIMING 0
+#endif
+#if WS_TIMING
+#define WS_TICK(i) do { asm volatile("s_nop 0" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[i] += tn_ - tm0; tm0 = tn_; } while (0)
+#else
+#define WS_TICK(i) do {} while (0)
+#endif
 // CM x CN consumer waves over the tile.  LN = 1: folded LayerNorm, row form, statistics handed over by the GEMM that wrote the
 // token rows (imh_lnstats.h): before their first hand-over the consumer threads merge the slot partials of the tile's BM rows
 // (one thread per row, loads in flight beside the producers' ring prologue) into an LDS area behind the ring -- no statistics
@@ -518,14 +529,27 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = S - 1;                                     // slot of tile i + S - 1
+#if WS_TIMING
+        unsigned long long tacc[3] = {0, 0, 0}, tm0 = __builtin_readcyclecounter();
+#endif
         for (int i = 0; i < nt; ++i) {
             if (i + S - 1 < nt) issue(slot, kt0 + i + S - 1); // the slot tile i - 1 was read from
+            WS_TICK(0);
             if (i + S <= nt) wait_vmcnt<(S - 2) * LP>();      // tile i + 1 has landed
             else wait_vmcnt<0>();
+            WS_TICK(1);
             __builtin_amdgcn_s_barrier();
+            WS_TICK(2);
             if (++slot == S) slot = 0;
         }
+#if WS_TIMING
+        if (bid == 0 && pw == 0 && lane == 0 && p.pf_ptr) {
+            unsigned long long* dbg = (unsigned long long*)p.pf_ptr + 4;
+            dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = nt;
+        }
+#else
         if (z == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, bid, nblocks, tid - 64 * NC, 64 * NL);
+#endif
         return;
     }
 
@@ -603,6 +627,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     __builtin_amdgcn_s_barrier();                  // tile 0 has landed
     asm volatile("" ::: "memory");
     int slot = 0;
+#if WS_TIMING
+    unsigned long long tacc[3] = {0, 0, 0}, tm0 = __builtin_readcyclecounter();
+#endif
     for (int i = 0; i < nt; ++i) {
         rd(K0, slot);                              // (i, k step 0)  beside the MFMAs of (i - 1, k step 1)
         if (i > 0) mm(K1);
@@ -612,13 +639,22 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         mm(K0);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
+        WS_TICK(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile i has been read: its slot may be refilled
+        WS_TICK(1);
         __builtin_amdgcn_s_barrier();                            // ... and tile i + 1 has landed
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        WS_TICK(2);
         if (++slot == S) slot = 0;
     }
     if (nt > 0) mm(K1);
+#if WS_TIMING
+    if (bid == 0 && wave == 0 && lane == 0 && p.pf_ptr) {
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr;
+        dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = nt;
+    }
+#endif
 
     const int nb = n0 + wn * TN + (lane >> 4) * 4 * FN;
     // s_n, c_n (folded LayerNorm) or the bias of this lane's columns: fetched once, ahead of the stores (EpiPre; the LN

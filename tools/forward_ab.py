@@ -58,7 +58,9 @@ CONFIGS = collections.OrderedDict([
     # the round-3 launch structure as far as it can still be selected: [Q|K] + V^T two-problem launch, GroupNorm as table + apply
     # passes in front of every conv (the erf-GELU polynomial and the statistics-only LayerNorm hand-over cannot be switched back)
     ("round3_like", dict(qkv_one=False, gn_fuse=False)),
-    # (measured with this tool and removed from the tree again, results kept: the halo waves of the LDS-halo conv as full producer
+    # (measured with this tool and removed from the tree again, results kept: ff.net.0 / [Q|K|V] on FOUR consumer waves of 128 x 80 with
+    # streamed token fragments (29 % fewer LDS fragment bytes per K tile) -- profiles/r04_forward_ab_wave_tile_128x80.json: bit-identical,
+    # [Q|K|V] the same, ff.net.0 68 -> 93 us; the halo waves of the LDS-halo conv as full producer
     # waves that also run the weight ring, and the MFMA waves' (chunk, tap) loop software-pipelined like the wave-specialised GEMM's
     # consumers -- profiles/r04_forward_ab_halo_producer_waves.json (8-11 % slower), r04_forward_ab_halo_pipelined_loop*.json (flat); the [Q|K|V] column tiles dealt to the XCDs by head
     # group so that Q, K, V of a head are written on the XCD that reads them -- profiles/r04_forward_ab_qkv_xcd_affinity.json, no
