@@ -442,6 +442,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+#if WS_TIMING
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same counter on every XCD
+#endif
     int m0, n0;
     if (!xcd_tile<BM, BN>(p, bid, m0, n0)) return;     // the whole workgroup exits together
     const int nkt = p.K / GEMM_BK;
@@ -629,6 +632,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     int slot = 0;
 #if WS_TIMING
     unsigned long long tacc[3] = {0, 0, 0}, tm0 = __builtin_readcyclecounter();
+    const unsigned long long ts_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int i = 0; i < nt; ++i) {
         rd(K0, slot);                              // (i, k step 0)  beside the MFMAs of (i - 1, k step 1)
@@ -650,9 +654,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     }
     if (nt > 0) mm(K1);
 #if WS_TIMING
+    const unsigned long long ts_loop1 = __builtin_amdgcn_s_memrealtime();
     if (bid == 0 && wave == 0 && lane == 0 && p.pf_ptr) {
         unsigned long long* dbg = (unsigned long long*)p.pf_ptr;
         dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = nt;
+    }
+    // every workgroup (pf_bytes == 0xfeed): [entry, K loop begin, K loop end] of consumer wave 0 on the chip-wide 100 MHz counter
+    if (wave == 0 && lane == 0 && p.pf_ptr && p.pf_bytes == 0xfeed) {
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + 8 + (size_t)bid * 4;
+        dbg[0] = ts_entry; dbg[1] = ts_loop0; dbg[2] = ts_loop1; dbg[3] = 0;
     }
 #endif
 

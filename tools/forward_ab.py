@@ -58,7 +58,9 @@ CONFIGS = collections.OrderedDict([
     # the round-3 launch structure as far as it can still be selected: [Q|K] + V^T two-problem launch, GroupNorm as table + apply
     # passes in front of every conv (the erf-GELU polynomial and the statistics-only LayerNorm hand-over cannot be switched back)
     ("round3_like", dict(qkv_one=False, gn_fuse=False)),
-    # (measured with this tool and removed from the tree again, results kept: ff.net.0 / [Q|K|V] on FOUR consumer waves of 128 x 80 with
+    # (measured with this tool and removed from the tree again, results kept: ff.net.0 as 256 PERSISTENT workgroups walking two tiles
+    # each (the producers stream the next tile while the consumers are in the epilogue) -- profiles/r04_forward_ab_persistent_geglu.json:
+    # bit-identical, 57.3 vs 57.6 us warm, 75.9 vs 64.6 us in the forward; ff.net.0 / [Q|K|V] on FOUR consumer waves of 128 x 80 with
     # streamed token fragments (29 % fewer LDS fragment bytes per K tile) -- profiles/r04_forward_ab_wave_tile_128x80.json: bit-identical,
     # [Q|K|V] the same, ff.net.0 68 -> 93 us; the halo waves of the LDS-halo conv as full producer
     # waves that also run the weight ring, and the MFMA waves' (chunk, tap) loop software-pipelined like the wave-specialised GEMM's
@@ -118,7 +120,7 @@ def main():
             lib.imh_debug_set(4, int(c.get("attn", 0)))
             lib.imh_debug_set(2, int(c.get("xcd", 0)))
             lib.imh_debug_set(5, int(c.get("halo", 0)))
-            ms = rec.time_ops()
+                ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
