@@ -4,6 +4,8 @@
 //   barrier   : ONE persistent launch, a grid barrier between phases (agent-scope release before arriving, acquire after leaving:
 //               the eight XCD L2s are not coherent with each other inside a kernel, so the release writes dirty lines back
 //               (buffer_wbl2 sc1) and the acquire invalidates (buffer_inv sc1))
+//   graph_nontemporal_stores : the graph form with `global_store ... nt` outputs (do they leave the L2 earlier than the end-of-kernel
+//               write-back? no: the same to 1 %, slower at 64 MB per phase)
 //   dataflow  : ONE persistent launch, no barrier: a workgroup waits only for the flag of the workgroup whose slice it reads
 //               (same release / acquire pair per dependency)
 // Every phase: workgroup i reads the SLICE bytes workgroup (i * 37 + 11) % G wrote in the previous phase, adds one, writes its
@@ -35,6 +37,24 @@ __device__ __forceinline__ void do_phase(const float4* in, float4* out, int i, i
 
 __global__ __launch_bounds__(512) void phase_kernel(const float4* in, float4* out, int n4, int work) {
     do_phase(in, out, blockIdx.x, gridDim.x, n4, work);
+}
+
+// the same phase with NON-TEMPORAL stores (global_store ... nt): the output does not sit dirty in the XCD's L2 until the end-of-kernel
+// write-back, it streams out while the phase runs
+typedef __attribute__((ext_vector_type(4))) float f4v;
+__global__ __launch_bounds__(512) void phase_nt_kernel(const float4* in, float4* out, int n4, int work) {
+    const int i = blockIdx.x, G = gridDim.x;
+    const f4v* s = (const f4v*)in + (size_t)src_of(i, G) * n4;
+    f4v* d = (f4v*)out + (size_t)i * n4;
+    for (int k = threadIdx.x; k < n4; k += blockDim.x) {
+        f4v v = s[k];
+        for (int w = 0; w < work; ++w) {
+            v.y = v.y * 1.0000001f + 1e-9f;
+            asm volatile("" : "+v"(v.y));
+        }
+        v.x += 1.f;
+        __builtin_nontemporal_store(v, d + k);
+    }
 }
 
 __global__ __launch_bounds__(512) void barrier_kernel(float4* buf, unsigned* ctr, int n4, int work, int phases) {
@@ -133,7 +153,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     unsigned* ctr;
     CK(hipMalloc(&ctr, (G + 1) * sizeof(unsigned)));
-    for (int slice_kb : {8, 64}) {
+    for (int slice_kb : {8, 64, 256}) {
         const int n4 = slice_kb * 1024 / 16;
         float4* buf;
         CK(hipMalloc(&buf, (size_t)2 * G * n4 * sizeof(float4)));
@@ -146,8 +166,15 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL(phase_kernel, dim3(G), dim3(T), 0, st, buf + (size_t)(p & 1) * G * n4, buf + (size_t)((p + 1) & 1) * G * n4, n4, work);
             CK(hipStreamEndCapture(st, &g));
             CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-            bool ok[4] = {true, true, true, true};
+            float best[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+            bool ok[5] = {true, true, true, true, true};
+            hipGraph_t g2;
+            hipGraphExec_t ge2;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int p = 0; p < phases; ++p)
+                hipLaunchKernelGGL(phase_nt_kernel, dim3(G), dim3(T), 0, st, buf + (size_t)(p & 1) * G * n4, buf + (size_t)((p + 1) & 1) * G * n4, n4, work);
+            CK(hipStreamEndCapture(st, &g2));
+            CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
             hipLaunchKernelGGL(spin_kernel, dim3(1024), dim3(512), 0, st, (float*)ctr, 4000000);
             for (int r = 0; r < reps; ++r) {
                 float ms;
@@ -189,9 +216,18 @@ int main(int argc, char** argv) {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best[3]) best[3] = ms;
                 if (r == 0) ok[3] = check(buf, G, n4, phases);
+
+                CK(hipMemsetAsync(buf, 0, (size_t)2 * G * n4 * sizeof(float4), st));
+                CK(hipEventRecord(e0, st));
+                CK(hipGraphLaunch(ge2, st));
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best[4]) best[4] = ms;
+                if (r == 0) ok[4] = check(buf, G, n4, phases);
             }
-            const char* names[4] = {"graph", "barrier", "dataflow", "barrier_one_fence"};
-            for (int m = 0; m < 4; ++m)
+            const char* names[5] = {"graph", "barrier", "dataflow", "barrier_one_fence", "graph_nontemporal_stores"};
+            for (int m = 0; m < 5; ++m)
                 printf("%s,%d,%d,%d,%d,%d,%.3f,%d\n", names[m], G, T, slice_kb, work, phases, best[m] * 1e3f / phases, ok[m] ? 1 : 0);
             CK(hipGraphExecDestroy(ge));
             CK(hipGraphDestroy(g));
