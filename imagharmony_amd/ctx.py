@@ -187,6 +187,16 @@ class Ctx:
             return False
         return True
 
+    def _xcd_for(self, N, flags, conv):
+        """imh_gemm_args.xcd of one launch under this context's policy (xcd_cells): 0 / 2..5 = the same request for every launch;
+        1x = x for every launch except the GEGLU ones (model).  (A policy that asked for whole-row cells only on the Linear launches
+        with small weights -- N <= 1280 -- measured no different from the model on two boxes where 4 x 2 / 8 x 1 EVERYWHERE were 0.2-1.0
+        ms ahead: profiles/r04_forward_ab_xcd_policies_box*.json; dropped.)"""
+        pol, cells = divmod(self.xcd_cells, 10)
+        if pol == 1 and flags & L.GF_GEGLU:
+            return 0
+        return cells
+
     def _config(self, M, N, K, conv, flags, stride=1, ln_pre=False):
         """tile variant of a launch: the tuning table's entry for the shape if that variant implements the launch's flags
         (folded LayerNorm in either form, V^T permutation, conv stride), else the built-in heuristic -- in ONE place"""
@@ -284,7 +294,7 @@ class Ctx:
         a.ldra = ldra
         a.rows_per_batch = rows_per_batch
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, flags, self.dt, 0, bm, bn
-        a.xcd = self.xcd_cells % 10 if not (self.xcd_cells >= 10 and flags & L.GF_GEGLU) else 0
+        a.xcd = self._xcd_for(N, flags, 0)
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
         st = None
@@ -416,7 +426,7 @@ class Ctx:
         a.ldra = ldra
         a.rows_per_batch = Ho * Wo
         a.splits, a.flags, a.dtype, a.conv, a.bm, a.bn = sp, 0, self.dt, 1, bm, bn
-        a.xcd = self.xcd_cells % 10
+        a.xcd = self._xcd_for(N, 0, 1)
         a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
         if x2 is not None:
             a.X2, a.Cin1 = x2.data_ptr(), C1

@@ -69,7 +69,7 @@ CONFIGS = collections.OrderedDict([
     # change; an L2 warm-up touch of the head's K / V^T lines at entry of the attention kernels --
     # profiles/r04_forward_ab_attn_kv_warmup.json, +1.8 / +0.8 us per launch)
     # XCD cell shape forced for EVERY GEMM / conv launch (imh_debug_set key 2): (8,1) (4,2) (2,4) (1,8) = M x N cells; read per op
-    ("cells13", dict(cells=13)), ("cells3", dict(cells=3)),      # Ctx.xcd_cells (the per-launch request, as DenoiseEngine picks it)
+    ("cells13", dict(cells=13)), ("cells3", dict(cells=3)), ("cells2", dict(cells=2)),      # Ctx.xcd_cells (the per-launch request, as DenoiseEngine picks it)
     ("base_again", dict()),                            # position control: the same configuration twice in one interleaved round
     ("xcd81", dict(xcd=2)), ("xcd42", dict(xcd=3)), ("xcd24", dict(xcd=4)), ("xcd18", dict(xcd=5)),
     ("xcd_m2", dict(xcd=6)), ("xcd_m3", dict(xcd=7)),   # the cost model restricted to (8,1) (4,2) / to (8,1) (4,2) (2,4)
@@ -120,7 +120,7 @@ def main():
             lib.imh_debug_set(4, int(c.get("attn", 0)))
             lib.imh_debug_set(2, int(c.get("xcd", 0)))
             lib.imh_debug_set(5, int(c.get("halo", 0)))
-                ms = rec.time_ops()
+            ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
