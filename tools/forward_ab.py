@@ -58,7 +58,10 @@ CONFIGS = collections.OrderedDict([
     # the round-3 launch structure as far as it can still be selected: [Q|K] + V^T two-problem launch, GroupNorm as table + apply
     # passes in front of every conv (the erf-GELU polynomial and the statistics-only LayerNorm hand-over cannot be switched back)
     ("round3_like", dict(qkv_one=False, gn_fuse=False)),
-    # (measured with this tool and removed from the tree again, results kept: ff.net.0 as 256 PERSISTENT workgroups walking two tiles
+    # (measured with this tool and removed from the tree again, results kept: the attention / fused cross-attention work items dealt to
+    # the XCDs by query rows instead of by head, alone and with 8 x 1 cells on the Linears ("token rows stay on an XCD") --
+    # profiles/r04_forward_ab_attention_items_by_rows_box*.json: the fused cross-attention 1-1.4 us faster per launch, the forward the
+    # same to 0.01 ms; ff.net.0 as 256 PERSISTENT workgroups walking two tiles
     # each (the producers stream the next tile while the consumers are in the epilogue) -- profiles/r04_forward_ab_persistent_geglu.json:
     # bit-identical, 57.3 vs 57.6 us warm, 75.9 vs 64.6 us in the forward; ff.net.0 / [Q|K|V] on FOUR consumer waves of 128 x 80 with
     # streamed token fragments (29 % fewer LDS fragment bytes per K tile) -- profiles/r04_forward_ab_wave_tile_128x80.json: bit-identical,
