@@ -43,6 +43,18 @@ constexpr int CH_HW = CH_PW + 2;                          // halo row length (18
 // which also waited for the next chunk's halo although it has nine steps of slack; now the weights are an S-slot ring with
 // COUNTED vmcnt (S - 2 steps and, where one was issued inside the window, the next halo stay in flight across the barrier).
 // S = 3 / 4 fit for the 160-cout form (107 / 127 KB); the 320-cout form stays at S = 2 (126 KB).
+// CH_TIMING (tools/halo_phase_probe.py only): cycle counter at the segment boundaries of the (chunk, tap) loop; MFMA wave 0 and halo wave 0 of
+// workgroup 0 write their per-segment totals to p.pf_ptr instead of prefetching --
+//   MFMA wave: [counted vmcnt] [s_barrier] [weight LDS-DMA issue (+ eight-wave form: halo issue / transform)] [fragment reads + MFMAs]
+//   halo wave: [lgkmcnt(0)] [s_barrier] [halo LDS-DMA issue / wait / in-place transform]
+#ifndef CH_TIMING
+#define CH_TIMING 0
+#endif
+#if CH_TIMING
+#define CH_TICK(i) do { asm volatile("s_nop 0" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[i] += tn_ - tm0; tm0 = tn_; } while (0)
+#else
+#define CH_TICK(i) do {} while (0)
+#endif
 __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
     switch (n) {       // wave-uniform; the immediate must be a literal
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -70,7 +82,12 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
 // 16 x 16 patch) no longer stall a wave that feeds the matrix pipe (with all of it inside the MFMA waves the fused launch ran
 // 13-21 us longer than the plain conv -- exactly what the stand-alone apply pass costs; profiles/r04_forward_ab_qkv_gn.json).
 // One s_barrier per (chunk, tap) step carries every hand-over, as before.
-template <typename T, int FN, int FM, int S, int HWV>
+// KS (round 5, the 32 x 32 latent): the two waves of a patch-row pair split the K range instead of the couts -- wave (wm, kh) takes k step
+// kh of every (chunk, tap) tile for ALL 16 FN couts of the workgroup, the pair's accumulators are added once through the (dead) LDS after
+// the loop.  A workgroup then owns 128 pixels x 80 couts: at M = 2048 pixels x 1280 couts that is 256 workgroups (one per CU) pulling
+// 10 KB of weights + 2.6 KB of halo per 80-MFMA step, where the 64 x 160 implicit GEMM pulls 28 KB (the L2 -> LDS stream is the bound of
+// that kernel: tools/micro/lds_port.hip) and the 4 x 16-patch x 160-cout form of round 4 read six fragments per five MFMAs.
+template <typename T, int FN, int FM, int S, int HWV, bool KS = false>
 __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
     constexpr int NSTG = HWV ? HWV : 8;                     // waves that stage the halo
     constexpr int CH_PH = 4 * FM;                           // output patch height
@@ -78,10 +95,19 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     constexpr int HPIECES = (CH_HALO + 7) / 8;              // 23 / 14 staging pieces of 8 halo pixels
     constexpr int HQ = (HPIECES + NSTG - 1) / NSTG;         // ... per staging wave
     constexpr int CH_HALO_BYTES = HPIECES * 8 * GEMM_ROW_BYTES;
-    constexpr int CH_BN = 32 * FN;
-    constexpr int CH_W_BYTES = CH_BN * GEMM_ROW_BYTES;
-    constexpr int WPIECES = CH_BN / 8;                      // 8-row staging pieces of the weight tile
+    constexpr int CH_BN = (KS ? 16 : 32) * FN;
+    // TPS = taps per step.  One step = one s_barrier, one counted vmcnt, one round of weight LDS-DMA issue by the MFMA waves -- measured
+    // (tools/halo_phase_probe.py, profiles/r05_halo_phase_probe.txt) at 1000-1400 cycles per step on top of the MFMAs, whatever the tile.
+    // The KS form's step is only 10 MFMAs per wave, so it takes a whole kernel ROW per step (ky = step of the chunk, kx = 0 .. 2): the
+    // weight stage holds three [80 x 64] tap tiles (30 KB, three slots).
+    constexpr int TPS = KS ? 3 : 1;
+    constexpr int SPC = 9 / TPS;                            // steps per chunk
+    constexpr int CH_TAP_BYTES = CH_BN * GEMM_ROW_BYTES;    // one tap's weight tile
+    constexpr int CH_W_BYTES = TPS * CH_TAP_BYTES;
+    constexpr int TPIECES = CH_BN / 8;                      // 8-row staging pieces of one tap's weight tile
+    constexpr int WPIECES = TPS * TPIECES;                  // ... of a step
     constexpr int WQ = (WPIECES + 7) / 8;                   // ... per wave
+    static_assert(!KS || HWV > 0, "the KS form runs with halo waves");
     typedef typename Vec<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo0 = smem;
@@ -159,24 +185,28 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
             }
         }
     };
-    // ---- weight staging: 40 pieces of 8 rows; this wave takes pieces wave + 8 q ----
+    // ---- weight staging: WPIECES pieces of 8 rows per step (tap-major); this wave takes pieces wave + 8 q ----
     const unsigned char* wsrc[WQ];
-    int wstep[WQ];
+    int wstep[WQ], wtap[WQ];
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
-        const int row = (q * 8 + wave) * 8 + (lane >> 3);
+        const int piece = q * 8 + (wave & 7);
+        wtap[q] = piece / TPIECES;                          // tap of the step this piece belongs to
+        const int row = (piece - wtap[q] * TPIECES) * 8 + (lane >> 3);
         const int c = stage_chunk_w(row, lane, FN);
-        const bool ok = q * 8 + wave < WPIECES && n0 + row < p.N;
+        const bool ok = piece < WPIECES && n0 + row < p.N;
         wsrc[q] = ok ? (const unsigned char*)p.W + (size_t)(n0 + row) * p.ldw * sizeof(T) + c * 16 : g_zero_page + c * 16;
         wstep[q] = ok ? GEMM_BK * (int)sizeof(T) : 0;
     }
     const int cpt = p.Cin / GEMM_BK;                        // 64-channel chunks
-    auto stage_w = [&](int buf, int ct, int tap) {
+    auto stage_w = [&](int buf, int ct, int st) {           // st: step of the chunk = first tap / TPS
         unsigned char* d = wbuf0 + buf * CH_W_BYTES;
-        const size_t kt = (size_t)tap * cpt + ct;           // packed weight K index = (ky*3 + kx) * Cin + c
 #pragma unroll
         for (int q = 0; q < WQ; ++q)
-            if (q * 8 + wave < WPIECES) glds16(wsrc[q] + kt * wstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+            if (q * 8 + wave < WPIECES) {
+                const size_t kt = (size_t)(st * TPS + wtap[q]) * cpt + ct;      // packed weight K index = (ky*3 + kx) * Cin + c
+                glds16(wsrc[q] + kt * wstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+            }
     };
 
     // ---- fragment read offsets ----
@@ -185,8 +215,8 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     int woff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        const int wr = wn * (16 * FN) + w_frag_row(lane & 15, 0, FN);
-        woff[kk] = tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+        const int wr = (KS ? 0 : wn * (16 * FN)) + w_frag_row(lane & 15, 0, FN);
+        woff[kk] = tile_off(wr, (KS ? wn : kk) * 4 + (lane >> 4), swz_w(wr, FN));     // KS: this wave's k step is wn, whatever kk
     }
 
     f32x4 acc[FM][FN];
@@ -195,11 +225,11 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = 9 * cpt;
+    const int nsteps = SPC * cpt;
     // LDS-DMA instructions this wave issues per weight step / per halo (wave-uniform: the last round of pieces is ragged)
-    const int nW = (WQ - 1) + ((WQ - 1) * 8 + (wave & 7) < WPIECES ? 1 : 0);
+    const int nW = (WQ - 1) + ((WQ - 1) * 8 + (wave & 7) < WPIECES ? 1 : 0);      // (per step)
     const int nH = HWV ? 0 : (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
-    auto step_ct = [&](int st) { return st / 9; };
+    auto step_ct = [&](int st) { return st / SPC; };
     const bool gn = p.gn_tab != nullptr;
     if (gn) {                                           // this sample's (scale, shift) table -> LDS, before any LDS-DMA is in flight
         const f32x4* src = (const f32x4*)(p.gn_tab + (size_t)b * p.Cin * 2);
@@ -214,47 +244,70 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
             stage_halo(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (gn) norm_halo(0, 0, 0, HQ);
+#if CH_TIMING
+            unsigned long long tacc[4] = {0, 0, 0, 0}, tm0 = __builtin_readcyclecounter();
+#endif
             for (int ct = 0; ct < cpt; ++ct) {
 #pragma unroll 1
-                for (int tap = 0; tap < 9; ++tap) {
+                for (int tap = 0; tap < SPC; ++tap) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's in-place writes are in LDS ...
+                    CH_TICK(0);
                     __builtin_amdgcn_s_barrier();                        // ... before the step that may read them; the halo buffer
                     asm volatile("" ::: "memory");                       // of chunk ct - 1 is free from (ct, tap 0) on
+                    CH_TICK(1);
                     if (ct + 1 < cpt) {
                         if (tap == 0) stage_halo((ct + 1) & 1, ct + 1);
-                        if (tap == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // two steps of flight
-                        if (gn && tap >= 2) norm_halo((ct + 1) & 1, ct + 1, (tap - 2) * PPT, (tap - 1) * PPT);
+                        if constexpr (TPS == 1) {
+                            if (tap == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // two steps of flight
+                            if (gn && tap >= 2) norm_halo((ct + 1) & 1, ct + 1, (tap - 2) * PPT, (tap - 1) * PPT);
+                        } else {                             // three long steps per chunk: issue / first half / second half
+                            if (tap == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (gn && tap >= 1) norm_halo((ct + 1) & 1, ct + 1, (tap - 1) * ((HQ + 1) / 2), tap * ((HQ + 1) / 2));
+                        }
                     }
+                    CH_TICK(2);
                 }
             }
+#if CH_TIMING
+            if (blockIdx.x == 0 && wave == 8 && lane == 0 && p.pf_ptr) {
+                unsigned long long* dbg = (unsigned long long*)p.pf_ptr + 8;
+                dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = SPC * cpt;
+            }
+#else
             tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 512, 64 * HWV);
+#endif
             return;
         }
     }
     if constexpr (HWV == 0) stage_halo(0, 0);           // oldest: whoever waits for weight step 0 has the first halo too
 #pragma unroll
     for (int j = 0; j < S - 1; ++j)
-        if (j < nsteps) stage_w(j % S, step_ct(j), j - 9 * step_ct(j));
+        if (j < nsteps) stage_w(j % S, step_ct(j), j - SPC * step_ct(j));
     if (HWV == 0 && gn) {                               // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
         wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
         norm_halo(0, 0, 0, HQ);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written back before the barrier of step 0 publishes the halo
     }
     int step = 0;
+#if CH_TIMING
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tm0 = __builtin_readcyclecounter();
+#endif
     for (int ct = 0; ct < cpt; ++ct) {
         const unsigned char* hb = halo0 + (ct & 1) * CH_HALO_BYTES;
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++step) {
+        for (int tap = 0; tap < SPC; ++tap, ++step) {       // (TPS == 1: tap = the tap; TPS == 3: the kernel row ky)
             // weight step `step` must have landed.  Younger loads that may stay in flight: the weight steps behind it (at most
             // S - 2) and the next chunk's halo if it was issued inside that window (at tap 0 of this chunk, taps 1 .. S - 1 ago)
             const int ahead = min(S - 2, nsteps - 1 - step);
             const int halo_in_window = (HWV == 0 && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
             wait_vmcnt_dyn(ahead * nW + halo_in_window);
+            CH_TICK(0);
             __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
             asm volatile("" ::: "memory");
+            CH_TICK(1);
             if (step + S - 1 < nsteps) {
                 const int ns = step + S - 1, nct = step_ct(ns);
-                stage_w(ns % S, nct, ns - 9 * nct);                  // into the slot of step - 1
+                stage_w(ns % S, nct, ns - SPC * nct);                // into the slot of step - 1
             }
             if constexpr (HWV == 0) {
                 if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
@@ -264,33 +317,68 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
                 // beside its 40 MFMAs per wave
                 if (gn && tap >= S && tap < S + HQ && ct + 1 < cpt) norm_halo((ct + 1) & 1, ct + 1, tap - S, tap - S + 1);
             }
-            const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES;
-            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;     // tap / 3 for tap < 9
+            CH_TICK(2);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                v8 xf[FM], wf[FN];
+            for (int tp = 0; tp < TPS; ++tp) {
+                const unsigned char* wb = wbuf0 + (step % S) * CH_W_BYTES + tp * CH_TAP_BYTES;
+                const int ky = TPS == 3 ? tap : ((tap * 11) >> 5);   // tap / 3 for tap < 9
+                const int kx = TPS == 3 ? tp : tap - ky * 3;
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int r = hrow0 + (i + ky) * CH_HW + kx;
-                    xf[i] = *(const v8*)(hb + r * GEMM_ROW_BYTES + (((kk * 4 + (lane >> 4)) ^ (r & 7)) << 4));
+                for (int kk = 0; kk < (KS ? 1 : 2); ++kk) {
+                    v8 xf[FM], wf[FN];
+                    const int kc = (KS ? wn : kk) * 4 + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int r = hrow0 + (i + ky) * CH_HW + kx;
+                        xf[i] = *(const v8*)(hb + r * GEMM_ROW_BYTES + ((kc ^ (r & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(wb + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
                 }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) wf[j] = *(const v8*)(wb + woff[kk] + j * 4 * GEMM_ROW_BYTES);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
             }
             asm volatile("" ::: "memory");
+            CH_TICK(3);
         }
     }
+#if CH_TIMING
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && p.pf_ptr) {
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr;
+        dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = tacc[3]; dbg[4] = nsteps;
+    }
+#endif
 
     // ---- epilogue: lane owns couts nb .. nb + 4 FN - 1 (40 or 20 consecutive channels = 80 / 40 B) of output pixel (oy, ox):
     //      the whole run goes through the shared vector epilogue at once -- bias / time-embedding row / residual fetched as
     //      16-B vectors once per run and the result stored as 16-B pieces.  (Round 2 stored 4-channel = 8-B pieces, 64
     //      different 128-B lines per store instruction: profiles/r02_pmc_hbm_traffic.json showed 3.2x write amplification on
     //      this kernel.)  Compile-time fragment indices only: a rolled loop would turn acc[][] into a scratch array.
-    const int nb = n0 + wn * (16 * FN) + (lane >> 4) * (4 * FN);
+    if constexpr (KS) {
+        // the pair's k halves: wave (wm, 1) hands its accumulators to (wm, 0) through LDS (everything staged there is dead once every
+        // MFMA wave has left the loop -- the halo waves are past their last barrier or gone) and leaves
+        f32x4* ex = (f32x4*)smem + (size_t)wm * (FM * FN) * 64 + lane;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wn == 1) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) ex[(i * FN + j) * 64] = acc[i][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wn == 1) return;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] += ex[(i * FN + j) * 64];
+    }
+    const int nb = n0 + (KS ? 0 : wn * (16 * FN)) + (lane >> 4) * (4 * FN);
     const int ox = tx * CH_PW + (lane & 15);
     // GroupNorm partials of the output for the GroupNorm that reads it (norm2 after conv1, the next block's norm after conv2):
     // a wave's FM patch rows x 16 pixels are one partial block
@@ -316,7 +404,9 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{});
     if (p.gn_out) gn_emit<4 * FN>(p.gn_out, p.gn_nblk, p.N / 10, b, (ty * tiles_x + tx) * 4 + wm, nb, gna, FM, lane);
-    if (HWV == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+#if !CH_TIMING
+    if (HWV == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);      // (KS: the surviving half of the waves)
+#endif
 }
 
 // variant codes (bm x bn fields of the config), conv only: 7128 = 8 x 16 patch, 7564 = 4 x 16 patch; bn = 320 | 160 couts;
@@ -326,9 +416,11 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
 // with a 2- / 3-slot weight ring
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
     const int ph = bm == 7564 ? 4 : ((bm == 7256 || bm == 7356) ? 16 : 8);
-    const int S = (bm == 7328 || bm == 7356) ? 3 : (bm == 7428 ? 4 : 2);
-    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160) || ((S > 2 || ph == 16) && bn != 160)) {
-        set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 (160 only for the 3- / 4-slot rings) (stride=%d splits=%d Cin=%d bm=%d bn=%d)", p.stride, p.splits, p.Cin, bm, bn);
+    const bool ks = bn == 80;                    // 8 x 16 patch x 80 couts, k halves per wave pair, three taps per step, 3-slot ring (7128 x 80 only)
+    const int S = ks ? 3 : ((bm == 7328 || bm == 7356) ? 3 : (bm == 7428 ? 4 : 2));
+    if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160 && bn != 80) || ((S > 2 || ph == 16) && bn != 160 && !ks) ||
+        (ks && bm != 7128)) {
+        set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 (160 only for the 3- / 4-slot rings) | 80 (7128 only) (stride=%d splits=%d Cin=%d bm=%d bn=%d)", p.stride, p.splits, p.Cin, bm, bn);
         return IMH_ERR_ARG;
     }
     if (p.Ho != (p.H << p.up) || p.Wo != (p.Wd << p.up)) { set_error("conv_halo: output size must equal the (upsampled) input size"); return IMH_ERR_SHAPE; }
@@ -341,17 +433,20 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         set_error("conv_halo: Cin1=%d must be a positive multiple of 64, = Cin=%d exactly when there is no second source", p.Cin1, p.Cin);
         return IMH_ERR_ARG;
     }
-    const int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * bn * GEMM_ROW_BYTES + (p.gn_tab ? p.Cin * 8 : 0);
+    int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * (ks ? 3 : 1) * bn * GEMM_ROW_BYTES + (p.gn_tab ? p.Cin * 8 : 0);
+    if (ks && lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;       // the pairs' accumulator exchange (40 KB) reuses the staging area
     if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
     // the fused GroupNorm front end runs on the form with four halo waves (the input side off the MFMA waves); g_halo_mode
     // (imh_debug_set key 5, A/B): 1 forces the eight-wave form, 2 the halo-wave form for every launch
     const bool hw4 = g_halo_mode == 2 || (g_halo_mode != 1 && p.gn_tab != nullptr);
-#define IMH_CH4(TT, FNV, FMV, SV, HV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV>; static DynLdsOnce lds_once; \
+#define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
+#define IMH_CH4(TT, FNV, FMV, SV, HV) IMH_CH5(TT, FNV, FMV, SV, HV, false)
 #define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) IMH_CH4(TT, FNV, FMV, SV, 4); else IMH_CH4(TT, FNV, FMV, SV, 0); } while (0)
 #define IMH_CH(TT) do { \
-        if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
+        if (ks) IMH_CH5(TT, 5, 2, 3, 4, true); \
+        else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
@@ -360,6 +455,7 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
 #undef IMH_CH
 #undef IMH_CH3
 #undef IMH_CH4
+#undef IMH_CH5
     return check_launch("conv_halo_kernel");
 }
 

@@ -385,7 +385,7 @@ class Ctx:
         if bm not in self._HALO or stride != 1 or up:
             return False
         ph = 4 if bm == 7564 else (16 if bm in (7256, 7356) else 8)
-        S = 3 if bm in (7328, 7356) else (4 if bm == 7428 else 2)
+        S = 9 if bn == 80 else (3 if bm in (7328, 7356) else (4 if bm == 7428 else 2))     # (7128 x 80: three slots of three tap tiles each)
         lds = 2 * (((ph + 2) * 18 + 7) // 8) * 8 * 128 + S * bn * 128 + (K // 9) * 8
         return lds <= 160 * 1024
 
@@ -653,13 +653,24 @@ class Ctx:
             return
         self._pf_done = True
         can = (L.OP_GEMM, L.OP_ATTN, L.OP_LAYERNORM, L.OP_GROUPNORM, L.OP_GEMM_DUAL, L.OP_XATTN)
+
+        def carries(i):
+            kind, a = self._ops[i][0], self._ops[i][1]
+            if kind not in can:
+                return False
+            # of the GroupNorm launches only the apply pass touches its prefetch slot (gn_apply_kernel); a table / statistics launch
+            # would swallow the pointer and the cold conv weights behind it would never be prefetched
+            if kind == L.OP_GROUPNORM and a.mode not in (L.GN_ALL, L.GN_APPLY):
+                return False
+            return True
+
         taken = set()
         for j, (kind, args, cold) in enumerate(self._ops):
             for (ptr, nb) in cold:
                 # nearest earlier launch with a free slot (measured better than handing big matrices to a longer,
                 # earlier kernel: 27.0 vs 27.3 ms per forward)
                 for i in range(j - 1, max(j - 4, -1), -1):
-                    if i in taken or self._ops[i][0] not in can:
+                    if i in taken or not carries(i):
                         continue
                     a = self._ops[i][1]
                     tgt = a[0] if self._ops[i][0] == L.OP_GEMM_DUAL else a

@@ -93,7 +93,8 @@ HALO_CASES = [dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 320, 1), ph=8)
               dict(B=1, H=16, W=16, Cin=64, Cout=1280, cfg=(7128, 320, 1), ph=8), dict(B=2, H=16, W=16, Cin=128, Cout=640, cfg=(7128, 160, 1), ph=8),
               dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7328, 160, 1), ph=8), dict(B=1, H=24, W=16, Cin=192, Cout=1280, cfg=(7428, 160, 1), ph=8),
               dict(B=2, H=32, W=32, Cin=128, Cout=320, cfg=(7256, 160, 1), ph=16), dict(B=1, H=16, W=32, Cin=64, Cout=640, cfg=(7356, 160, 1), ph=16),
-              dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1), ph=4), dict(B=1, H=12, W=32, Cin=64, Cout=640, cfg=(7564, 320, 1), ph=4)]
+              dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1), ph=4), dict(B=1, H=12, W=32, Cin=64, Cout=640, cfg=(7564, 320, 1), ph=4),
+              dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 80, 1), ph=8), dict(B=1, H=32, W=32, Cin=64, Cout=1280, cfg=(7128, 80, 1), ph=8)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -248,7 +249,9 @@ def _gn_conv_ref(x, gamma, beta, w4, bias, silu=True):
                                   dict(B=2, H=32, W=32, Cin=320, Cout=320, cfg=(7256, 160, 1)), dict(B=1, H=16, W=32, Cin=640, Cout=320, cfg=(7356, 160, 1)),
                                   dict(B=2, H=16, W=16, Cin=320, Cout=640, cfg=(7328, 160, 1)), dict(B=1, H=24, W=16, Cin=960, Cout=320, cfg=(7428, 160, 1)),
                                   dict(B=2, H=20, W=24, Cin=320, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=12, W=32, Cin=640, Cout=640, cfg=(7564, 320, 1)),
-                                  dict(B=2, H=13, W=19, Cin=320, Cout=320, cfg=(7128, 160, 1))])
+                                  dict(B=2, H=13, W=19, Cin=320, Cout=320, cfg=(7128, 160, 1)),
+                                  dict(B=2, H=16, W=32, Cin=320, Cout=320, cfg=(7128, 80, 1)), dict(B=1, H=13, W=19, Cin=640, Cout=240, cfg=(7128, 80, 1)),
+                                  dict(B=2, H=32, W=32, Cin=1280, Cout=160, cfg=(7128, 80, 1))])
 def test_conv_with_fused_groupnorm_silu(L, dtype, case):
     """ResnetBlock2D's norm -> SiLU -> conv in ONE launch on every LDS-halo variant (aligned and ragged images: the padding pixels
     must stay zero AFTER the normalisation), statistics from the producer-format pass, against torch; bitwise repeatable; the
@@ -283,7 +286,8 @@ def test_conv_with_fused_groupnorm_silu(L, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [dict(B=2, H=16, W=16, C1=640, C2=320, Cout=640, cfg=(7128, 160, 1)), dict(B=2, H=16, W=32, C1=320, C2=320, Cout=320, cfg=(7256, 160, 1)),
-                                  dict(B=1, H=16, W=16, C1=1280, C2=640, Cout=640, cfg=(7128, 160, 1)), dict(B=2, H=16, W=16, C1=640, C2=320, Cout=320, cfg=(7128, 320, 1))])
+                                  dict(B=1, H=16, W=16, C1=1280, C2=640, Cout=640, cfg=(7128, 160, 1)), dict(B=2, H=16, W=16, C1=640, C2=320, Cout=320, cfg=(7128, 320, 1)),
+                                  dict(B=2, H=16, W=16, C1=1280, C2=640, Cout=160, cfg=(7128, 80, 1)), dict(B=1, H=32, W=32, C1=1280, C2=1280, Cout=80, cfg=(7128, 80, 1))])
 def test_conv_over_a_two_source_concat_with_fused_groupnorm(L, dtype, case):
     """the up blocks' resnet: norm1(torch.cat([hidden, skip], 1)) -> SiLU -> conv1 with the concat read from its two producers and
     the GroupNorm statistics merged from the two tensors' partials (groups straddle the seam: 960 / 32 = 30, 1920 / 32 = 60 channels

@@ -195,6 +195,9 @@ def test_gemm_vt_perm(L, dtype, cfg):
                                   dict(B=2, H=32, W=32, Cin=128, Cout=320, cfg=(7256, 160, 1)), dict(B=1, H=20, W=12, Cin=64, Cout=200, up=1, cfg=(7356, 160, 1)),
                                   dict(B=1, H=24, W=40, Cin=192, Cout=160, cfg=(7356, 160, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(7564, 160, 1)), dict(B=1, H=10, W=20, Cin=64, Cout=384, cfg=(7564, 320, 1)),
+                                  # 8 x 16 patch x 80 couts, the wave pairs split K (round 5): aligned, ragged patch grid + ragged cout tile, fused upsampling
+                                  dict(B=2, H=16, W=32, Cin=128, Cout=320, cfg=(7128, 80, 1)), dict(B=1, H=12, W=20, Cin=192, Cout=200, cfg=(7128, 80, 1)),
+                                  dict(B=2, H=8, W=8, Cin=64, Cout=160, up=1, cfg=(7128, 80, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(1464, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(2464, 160, 1)),
                                   dict(B=1, H=24, W=24, Cin=64, Cout=160, stride=2, cfg=(2464, 160, 2)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(24128, 160, 1)), dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(22128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(24128, 128, 1))])

@@ -245,7 +245,7 @@ def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
         for a, b in re.findall(r"bm == (\d+) && bn == (\d+)", open(os.path.join(csrc, f)).read()):
             known.add((int(a), int(b)))
     pp = {8256: 256, 9128: 320, 9256: 320}                         # gemm_pp.hip: one tile shape per code
-    halo = {(7128, 320), (7128, 160), (7564, 320), (7564, 160), (7328, 160), (7428, 160), (7256, 160), (7356, 160)}    # conv_halo.hip: patch x couts, stride-1 conv only
+    halo = {(7128, 320), (7128, 160), (7128, 80), (7564, 320), (7564, 160), (7328, 160), (7428, 160), (7256, 160), (7356, 160)}    # conv_halo.hip: patch x couts, stride-1 conv only
     table = json.load(open(os.path.join(ROOT, "imagharmony_amd", "tuning.json")))
     assert len(table) >= 30
     for key, (bm, bn, splits) in table.items():

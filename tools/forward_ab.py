@@ -52,6 +52,9 @@ CONFIGS = collections.OrderedDict([
     # the 32 x 32 ResBlock convolutions on the 4 x 16-patch LDS-halo form (GroupNorm + SiLU + concat fused) instead of the
     # wave-specialised 64 x 160 implicit GEMM behind a table + apply pass
     ("conv32_7564", dict(tuning={f"2048,1280,{k},1": [7564, 160, 1] for k in (5760, 11520, 17280, 23040)})),
+    # round 5: the same convolutions on the 8 x 16-patch x 80-cout form whose wave pairs split the K range (conv_halo.hip KS)
+    ("conv32_ks80", dict(tuning={f"2048,1280,{k},1": [7128, 80, 1] for k in (5760, 11520, 17280, 23040)})),
+    ("conv32_ws", dict(tuning={f"2048,1280,{k},1": [2464, 160, 1] for k in (5760, 11520, 17280, 23040)})),
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
     ("qkv_one_1280", dict(qkv_one=True, qkv_widths=(1280,))),
