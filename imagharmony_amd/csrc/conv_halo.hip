@@ -56,24 +56,14 @@ constexpr int CH_HW = CH_PW + 2;                          // halo row length (18
 #define CH_TICK(i) do {} while (0)
 #endif
 __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
+#define IMH_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n) {       // wave-uniform; the immediate must be a literal
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        IMH_VMC(0) IMH_VMC(1) IMH_VMC(2) IMH_VMC(3) IMH_VMC(4) IMH_VMC(5) IMH_VMC(6) IMH_VMC(7) IMH_VMC(8) IMH_VMC(9) IMH_VMC(10) IMH_VMC(11)
+        IMH_VMC(12) IMH_VMC(13) IMH_VMC(14) IMH_VMC(15) IMH_VMC(16) IMH_VMC(17) IMH_VMC(18) IMH_VMC(19) IMH_VMC(20) IMH_VMC(21) IMH_VMC(22)
+        IMH_VMC(23) IMH_VMC(24) IMH_VMC(25) IMH_VMC(26) IMH_VMC(27) IMH_VMC(28) IMH_VMC(29) IMH_VMC(30)
+        default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
     }
+#undef IMH_VMC
 }
 
 // HWV = 0: eight waves do everything (rounds 2-3).  HWV = 4 (round 4): four extra HALO waves own the input side -- they issue the
@@ -87,8 +77,12 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
 // the loop.  A workgroup then owns 128 pixels x 80 couts: at M = 2048 pixels x 1280 couts that is 256 workgroups (one per CU) pulling
 // 10 KB of weights + 2.6 KB of halo per 80-MFMA step, where the 64 x 160 implicit GEMM pulls 28 KB (the L2 -> LDS stream is the bound of
 // that kernel: tools/micro/lds_port.hip) and the 4 x 16-patch x 160-cout form of round 4 read six fragments per five MFMAs.
-template <typename T, int FN, int FM, int S, int HWV, bool KS = false>
-__global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
+// SVC (round 5): the HWV extra waves are SERVICE waves -- they own every LDS-DMA of the launch (the weight ring with its counted vmcnt as
+// well as the halo) besides the in-place transform, and the eight MFMA waves only read fragments and issue MFMAs between barriers: an
+// MFMA wave that issues its share of the weight pieces right after the barrier queues behind the other waves' pieces in the CU's one
+// vector-memory front end for 400-600 cycles per step (profiles/r05_halo_phase_probe*.txt) before it reaches its first fragment read.
+template <typename T, int FN, int FM, int S, int HWV, bool KS = false, bool SVC = false>
+__global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 : 1)) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
     constexpr int NSTG = HWV ? HWV : 8;                     // waves that stage the halo
     constexpr int CH_PH = 4 * FM;                           // output patch height
     constexpr int CH_HALO = (CH_PH + 2) * CH_HW;            // 180 / 108 halo pixels
@@ -106,14 +100,16 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     constexpr int CH_W_BYTES = TPS * CH_TAP_BYTES;
     constexpr int TPIECES = CH_BN / 8;                      // 8-row staging pieces of one tap's weight tile
     constexpr int WPIECES = TPS * TPIECES;                  // ... of a step
-    constexpr int WQ = (WPIECES + 7) / 8;                   // ... per wave
+    constexpr int NWS = SVC ? HWV : 8;                      // waves that stage the weights
+    constexpr int WQ = (WPIECES + NWS - 1) / NWS;           // ... pieces per such wave
     static_assert(!KS || HWV > 0, "the KS form runs with halo waves");
+    static_assert(!SVC || HWV > 0, "service waves are the extra waves");
     typedef typename Vec<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo0 = smem;
     unsigned char* wbuf0 = smem + 2 * CH_HALO_BYTES;
     const float* const gtab = (const float*)(smem + 2 * CH_HALO_BYTES + S * CH_W_BYTES);     // [Cin][2] (scale, shift) of this sample (p.gn_tab)
-    static_assert(S >= 2 && (S - 2) * WQ + (HWV ? 0 : HQ) <= 15, "vmcnt switch range");
+    static_assert(S >= 2 && (S - 2) * WQ + ((HWV && !SVC) ? 0 : HQ) <= 31, "vmcnt switch range");
     static_assert(HWV ? (HQ <= 14) : (S + HQ <= 9), "the next chunk's halo is normalised piece by piece inside the current chunk's nine taps");
     constexpr int NT = 64 * (8 + HWV);
 
@@ -122,6 +118,7 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave & 7) >> 1, wn = wave & 1;
     const int sw = HWV ? wave - 8 : wave;                  // index among the halo-staging waves (negative: an MFMA wave of the HWV form)
+    const int widx = SVC ? (sw < 0 ? 0 : sw) : (wave & 7);  // index among the weight-staging waves
 
     // tile coordinates: cout tile fastest, then patch column, row, batch
     int t = blockIdx.x;
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
     int wstep[WQ], wtap[WQ];
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
-        const int piece = q * 8 + (wave & 7);
+        const int piece = q * NWS + widx;
         wtap[q] = piece / TPIECES;                          // tap of the step this piece belongs to
         const int row = (piece - wtap[q] * TPIECES) * 8 + (lane >> 3);
         const int c = stage_chunk_w(row, lane, FN);
@@ -199,14 +196,22 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
         wstep[q] = ok ? GEMM_BK * (int)sizeof(T) : 0;
     }
     const int cpt = p.Cin / GEMM_BK;                        // 64-channel chunks
-    auto stage_w = [&](int buf, int ct, int st) {           // st: step of the chunk = first tap / TPS
-        unsigned char* d = wbuf0 + buf * CH_W_BYTES;
-#pragma unroll
-        for (int q = 0; q < WQ; ++q)
-            if (q * 8 + wave < WPIECES) {
+    auto stage_w_q = [&](int buf, int ct, int st, auto Q) {      // piece Q of this wave; st: step of the chunk = first tap / TPS
+        constexpr int q = decltype(Q)::value;
+        if constexpr (q < WQ) {
+            if (q * NWS + widx < WPIECES) {
                 const size_t kt = (size_t)(st * TPS + wtap[q]) * cpt + ct;      // packed weight K index = (ky*3 + kx) * Cin + c
-                glds16(wsrc[q] + kt * wstep[q], d + (q * 8 + wave) * 8 * GEMM_ROW_BYTES);
+                glds16(wsrc[q] + kt * wstep[q], wbuf0 + buf * CH_W_BYTES + (q * NWS + widx) * 8 * GEMM_ROW_BYTES);
             }
+        }
+    };
+    auto stage_w = [&](int buf, int ct, int st) {
+        static_assert(WQ <= 10, "pieces per wave");
+        stage_w_q(buf, ct, st, std::integral_constant<int, 0>{}); stage_w_q(buf, ct, st, std::integral_constant<int, 1>{});
+        stage_w_q(buf, ct, st, std::integral_constant<int, 2>{}); stage_w_q(buf, ct, st, std::integral_constant<int, 3>{});
+        stage_w_q(buf, ct, st, std::integral_constant<int, 4>{}); stage_w_q(buf, ct, st, std::integral_constant<int, 5>{});
+        stage_w_q(buf, ct, st, std::integral_constant<int, 6>{}); stage_w_q(buf, ct, st, std::integral_constant<int, 7>{});
+        stage_w_q(buf, ct, st, std::integral_constant<int, 8>{}); stage_w_q(buf, ct, st, std::integral_constant<int, 9>{});
     };
 
     // ---- fragment read offsets ----
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
 
     const int nsteps = SPC * cpt;
     // LDS-DMA instructions this wave issues per weight step / per halo (wave-uniform: the last round of pieces is ragged)
-    const int nW = (WQ - 1) + ((WQ - 1) * 8 + (wave & 7) < WPIECES ? 1 : 0);      // (per step)
-    const int nH = HWV ? 0 : (HQ - 1) + ((HQ - 1) * 8 + wave < HPIECES ? 1 : 0);
+    const int nW = (WQ - 1) + ((WQ - 1) * NWS + widx < WPIECES ? 1 : 0);      // (per step)
+    const int nH = (HWV && !SVC) ? 0 : (HQ - 1) + ((HQ - 1) * NSTG + (sw < 0 ? 0 : sw) < HPIECES ? 1 : 0);
     auto step_ct = [&](int st) { return st / SPC; };
     const bool gn = p.gn_tab != nullptr;
     if (gn) {                                           // this sample's (scale, shift) table -> LDS, before any LDS-DMA is in flight
@@ -241,27 +246,49 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
         if (wave >= 8) {
             // ------------------------------------------------------------------ halo wave: the input side of every chunk
             constexpr int PPT = (HQ + 6) / 7;                   // pieces normalised per tap (taps 2 .. 8)
+            if constexpr (SVC) {                                // the weight ring's prologue: S - 1 steps in flight
+#pragma unroll
+                for (int j = 0; j < S - 1; ++j)
+                    if (j < nsteps) stage_w(j % S, step_ct(j), j - SPC * step_ct(j));
+            }
             stage_halo(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (gn) norm_halo(0, 0, 0, HQ);
 #if CH_TIMING
             unsigned long long tacc[4] = {0, 0, 0, 0}, tm0 = __builtin_readcyclecounter();
 #endif
+            int step = 0;
+            auto staged = [&](int st) { return (SVC && st + S - 1 < nsteps) ? nW : 0; };      // weight pieces this wave issues at step st
             for (int ct = 0; ct < cpt; ++ct) {
 #pragma unroll 1
-                for (int tap = 0; tap < SPC; ++tap) {
+                for (int tap = 0; tap < SPC; ++tap, ++step) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's in-place writes are in LDS ...
+                    if constexpr (SVC) {
+                        // weight step `step` has landed.  Younger loads of this wave that may stay in flight: the weight steps behind it
+                        // (at most S - 2) and the next chunk's halo if it was issued inside that window (at tap 0, behind that step's weights)
+                        const int ahead = min(S - 2, nsteps - 1 - step);
+                        wait_vmcnt_dyn(ahead * nW + ((tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0));
+                    }
                     CH_TICK(0);
                     __builtin_amdgcn_s_barrier();                        // ... before the step that may read them; the halo buffer
                     asm volatile("" ::: "memory");                       // of chunk ct - 1 is free from (ct, tap 0) on
                     CH_TICK(1);
+                    if constexpr (SVC) {
+                        if (step + S - 1 < nsteps) {
+                            const int ns = step + S - 1, nct = step_ct(ns);
+                            stage_w(ns % S, nct, ns - SPC * nct);        // into the slot of step - 1 (every MFMA wave has read it)
+                        }
+                    }
+                    // (interleaving the weight pieces with the transform of the halo pieces -- one LDS-DMA, one piece, ... -- and the halo
+                    // ahead of step 0's weights measured SLOWER: 96.0 vs 89.6 us per fused conv2 at 32 x 32, profiles/r05_halo_phase_probe.txt)
                     if (ct + 1 < cpt) {
                         if (tap == 0) stage_halo((ct + 1) & 1, ct + 1);
                         if constexpr (TPS == 1) {
-                            if (tap == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // two steps of flight
+                            // two steps of flight; behind the halo in this wave's queue: the weights issued at taps 1 and 2
+                            if (tap == 2) wait_vmcnt_dyn(staged(step - 1) + staged(step));
                             if (gn && tap >= 2) norm_halo((ct + 1) & 1, ct + 1, (tap - 2) * PPT, (tap - 1) * PPT);
                         } else {                             // three long steps per chunk: issue / first half / second half
-                            if (tap == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (tap == 1) wait_vmcnt_dyn(staged(step));
                             if (gn && tap >= 1) norm_halo((ct + 1) & 1, ct + 1, (tap - 1) * ((HQ + 1) / 2), tap * ((HQ + 1) / 2));
                         }
                     }
@@ -280,9 +307,11 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
         }
     }
     if constexpr (HWV == 0) stage_halo(0, 0);           // oldest: whoever waits for weight step 0 has the first halo too
+    if constexpr (!SVC) {
 #pragma unroll
-    for (int j = 0; j < S - 1; ++j)
-        if (j < nsteps) stage_w(j % S, step_ct(j), j - SPC * step_ct(j));
+        for (int j = 0; j < S - 1; ++j)
+            if (j < nsteps) stage_w(j % S, step_ct(j), j - SPC * step_ct(j));
+    }
     if (HWV == 0 && gn) {                               // chunk 0: wait for the own halo pieces only (the weight steps behind them stay in flight)
         wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
         norm_halo(0, 0, 0, HQ);
@@ -298,16 +327,20 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? 3 : (S == 2 ? 2 : 1)) void co
         for (int tap = 0; tap < SPC; ++tap, ++step) {       // (TPS == 1: tap = the tap; TPS == 3: the kernel row ky)
             // weight step `step` must have landed.  Younger loads that may stay in flight: the weight steps behind it (at most
             // S - 2) and the next chunk's halo if it was issued inside that window (at tap 0 of this chunk, taps 1 .. S - 1 ago)
-            const int ahead = min(S - 2, nsteps - 1 - step);
-            const int halo_in_window = (HWV == 0 && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
-            wait_vmcnt_dyn(ahead * nW + halo_in_window);
+            if constexpr (!SVC) {
+                const int ahead = min(S - 2, nsteps - 1 - step);
+                const int halo_in_window = (HWV == 0 && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
+                wait_vmcnt_dyn(ahead * nW + halo_in_window);
+            }
             CH_TICK(0);
             __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
             asm volatile("" ::: "memory");
             CH_TICK(1);
-            if (step + S - 1 < nsteps) {
-                const int ns = step + S - 1, nct = step_ct(ns);
-                stage_w(ns % S, nct, ns - SPC * nct);                // into the slot of step - 1
+            if constexpr (!SVC) {
+                if (step + S - 1 < nsteps) {
+                    const int ns = step + S - 1, nct = step_ct(ns);
+                    stage_w(ns % S, nct, ns - SPC * nct);            // into the slot of step - 1
+                }
             }
             if constexpr (HWV == 0) {
                 if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);   // next chunk's halo: nine steps of slack
@@ -438,14 +471,19 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
     // the fused GroupNorm front end runs on the form with four halo waves (the input side off the MFMA waves); g_halo_mode
     // (imh_debug_set key 5, A/B): 1 forces the eight-wave form, 2 the halo-wave form for every launch
-    const bool hw4 = g_halo_mode == 2 || (g_halo_mode != 1 && p.gn_tab != nullptr);
-#define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV>; static DynLdsOnce lds_once; \
+    // the four halo waves for every launch (round 5: the un-fused launches gain too -- upsample 8192 x 1280 x 11520 258 -> 245 us,
+    // profiles/r05_forward_ab_conv32_ks80.json `halo_w12`); g_halo_mode 1 = the eight-wave form (A/B)
+    const bool hw4 = g_halo_mode != 1;
+#define IMH_CH6(TT, FNV, FMV, SV, HV, KSV, SVCV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV, SVCV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
-#define IMH_CH4(TT, FNV, FMV, SV, HV) IMH_CH5(TT, FNV, FMV, SV, HV, false)
-#define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) IMH_CH4(TT, FNV, FMV, SV, 4); else IMH_CH4(TT, FNV, FMV, SV, 0); } while (0)
+#define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) IMH_CH6(TT, FNV, FMV, SV, HV, KSV, KSV)
+    // g_halo_mode == 3 (A/B): the four extra waves of the other forms as service waves too -- measured slower there (four issuing waves
+    // pull 20-40 KB of weights per step more slowly than eight: 22.14 vs 21.86 ms per forward, profiles/r05_forward_ab_halo_svc.json)
+#define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) { if (g_halo_mode == 3) IMH_CH6(TT, FNV, FMV, SV, 4, false, true); else IMH_CH6(TT, FNV, FMV, SV, 4, false, false); } \
+        else IMH_CH6(TT, FNV, FMV, SV, 0, false, false); } while (0)
 #define IMH_CH(TT) do { \
-        if (ks) IMH_CH5(TT, 5, 2, 3, 4, true); \
+        if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
         else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
@@ -454,8 +492,8 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     else IMH_CH(f16_t);
 #undef IMH_CH
 #undef IMH_CH3
-#undef IMH_CH4
 #undef IMH_CH5
+#undef IMH_CH6
     return check_launch("conv_halo_kernel");
 }
 

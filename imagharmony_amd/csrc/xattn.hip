@@ -36,6 +36,12 @@ int g_xattn_mode = 0;   // imh_debug_set key 3 (test / A-B only, not thread-safe
 
 constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
 
+// XA_TIMING (tools/xattn_phase_probe.py only): every workgroup stamps entry / end of the to_q K loop / end of the key loops / exit on the
+// chip-wide 100 MHz counter into p.pf_ptr[item * 4 ..] (instead of prefetching) -- the launch as a time line per workgroup
+#ifndef XA_TIMING
+#define XA_TIMING 0
+#endif
+
 // LNQ: norm2 folded into to_q, row statistics handed over (xp.ln_stats)
 template <typename T, int NPASS, bool LNQ>
 __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XAttnParams xp) {
@@ -59,6 +65,9 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     const int hb = item / gx, qblk = item - hb * gx;
     const int b = hb / p.H, h = hb - b * p.H;
     const int q0 = qblk * (32 * NW);
+#if XA_TIMING
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- prologue: Q^T = Wq_h X^T ----
     // staging: 4 LDS-DMA rows-of-8 for the wave's own 32 token rows, 2 for its quarter of the weight tile
@@ -126,6 +135,9 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // every wave is done with the projection stages: the K / V^T ring may reuse them
+#if XA_TIMING
+    const unsigned long long ts_proj = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- accumulators -> Q^T B-operand fragments of the key loop.  MFMA step sd = 2*dt + u contracts the 16 head dims
     //      [32 dt + 16 u, +16); lane half hi supplies accumulator registers 8u .. 8u+7 of block dt, i.e. dims
@@ -154,8 +166,19 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 
     f32x16 fin[2];
     attn_core<T, NW, NPASS>(p, smem, qf, b, h, wave, lane, item, fin);
+#if XA_TIMING
+    const unsigned long long ts_keys = __builtin_amdgcn_s_memrealtime();
+#endif
     attn_store<T, NW>(p, smem, fin, b, h, q0, wave, lane);
+#if XA_TIMING
+    if (tid == 0 && p.pf_ptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)item * 4;
+        dbg[0] = ts_entry; dbg[1] = ts_proj; dbg[2] = ts_keys; dbg[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#else
     tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+#endif
 }
 
 
