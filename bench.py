@@ -215,9 +215,20 @@ def resampler_extra(device, dtype):
         for _ in range(20):
             g.replay()
         torch.cuda.synchronize(device)
-        out["ms_per_call"][f"B={B}"] = {"eager": eager, "graph_replay": (time.perf_counter() - t0) / 20 * 1e3,
-                                        "outputs_finite": bool(torch.isfinite(yg.float()).all().item()),
-                                        "replay_equals_eager": bool(torch.equal(yg, y))}
+        row = {"eager": eager, "graph_replay": (time.perf_counter() - t0) / 20 * 1e3,
+               "outputs_finite": bool(torch.isfinite(yg.float()).all().item()), "replay_equals_eager": bool(torch.equal(yg, y))}
+        # what IPAdapterPlusXL.get_image_embeds runs since round 5 (imagharmony_amd.modules.Graphed: copy in, replay, clone out)
+        from imagharmony_amd.modules import Graphed
+        gm = Graphed(m)
+        ya = gm(x)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ya = gm(x)
+        torch.cuda.synchronize(device)
+        row["as_get_image_embeds_runs_it"] = (time.perf_counter() - t0) / 20 * 1e3
+        row["adapter_path_equals_eager"] = bool(torch.equal(ya, y))
+        out["ms_per_call"][f"B={B}"] = row
     out["note"] = ("once per image (twice with the unconditional branch, ip_adapter.py:413-416); ~45 launches of 1-16-row GEMMs, "
                    "LayerNorms and the LDS-resident 16 x 273 latent cross-attention: launch-latency-bound, not on the per-step path")
     return out
@@ -429,7 +440,15 @@ def main():
     pe, ne, po, no = cond
     pipe = StableDiffusionXLCustomPipeline(unet, scheduler=DDIMScheduler(), device=device, dtype=dtype)
     eng = pipe.engine
-    eng.set_conditioning(pe, ne, po, no, a.res, a.res, guidance_scale=5.0)
+    # per-image conditioning work (text / image-prompt K, V caches of the 70 cross-attention layers + the added-conditioning embedding:
+    # attention_processor.py:410-411,432-433 hoisted out of the step loop) -- outside `value`, reported as conditioning_prepare_ms
+    cond_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        tc = time.perf_counter()
+        eng.set_conditioning(pe, ne, po, no, a.res, a.res, guidance_scale=5.0)
+        torch.cuda.synchronize(device)
+        cond_ms.append((time.perf_counter() - tc) * 1e3)
     eng.set_schedule(pipe.scheduler, a.denoise_steps)
     lat_shape = (1, 4, a.res // 8, a.res // 8)
     noises = [pns.seed_latents(i * world + rank, lat_shape).to(device) for i in range(a.warmup + a.steps)]
@@ -492,7 +511,11 @@ def main():
     dt = time.perf_counter() - t0
     clocks = clk.stop() if clk else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    per_rank = [dt / a.steps * 1e3]
     if world > 1:
+        alld = [torch.empty_like(tmax) for _ in range(world)]
+        dist.all_gather(alld, tmax)                          # per-rank wall time: the first real multi-GPU run diagnoses itself
+        per_rank = [float(t.item()) / a.steps * 1e3 for t in alld]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         allscores = [torch.empty_like(torch.cat(scores)) for _ in range(world)]
         dist.all_gather(allscores, torch.cat(scores))        # final gather of the candidate scores
@@ -532,7 +555,7 @@ def main():
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
         try:
-            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
+            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
                                                                           "r01_pmc_hbm_traffic_final.json")) if os.path.exists(q))
             traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
             traffic_src = f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command with --denoise-steps 4)"
@@ -548,6 +571,14 @@ def main():
             "config": {"workload": f"SDXL UNet {a.res}x{a.res}, {a.denoise_steps} DDIM steps, CFG 5.0 (UNet batch 2), "
                                    f"IP-Adapter scale 1.0, {a.ip_tokens} image tokens, 1 PNS candidate seed per GPU per step",
                        "parallelism": f"candidates sharded x{world} (no per-step collective)", "outputs_finite": finite,
+                       "distributed": {"world_size_reported_by_backend": dist.get_world_size() if world > 1 else 1,
+                                       "backend": dist.get_backend() if world > 1 else None,
+                                       "per_rank_ms_per_step": per_rank,
+                                       "devices_visible": torch.cuda.device_count()},
+                       "conditioning_prepare_ms": {"first_call": cond_ms[0], "later_calls": cond_ms[1:],
+                                                   "note": "DenoiseEngine.set_conditioning: K / V caches of the 70 cross-attention layers (140 small GEMMs "
+                                                           "+ 20 for the image-prompt tokens), add_embedding; once per image / per PNS run, shared by every "
+                                                           "candidate seed; not in `value`"},
                        "value_counts": "denoised latents per second (the reference's output_type='latent'); the VAE decode + "
                                        "post-processing tail (custom_pipelines.py:365-386) is NOT in `value` -- its time is "
                                        "reported under vae_decode",
@@ -559,7 +590,9 @@ def main():
                                              "3 = 4 x 2, 2 = 8 x 1 cells over M x N; bit-identical results, box-dependent speed"},
                        "tflop_per_unet_forward": tot_fl / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "frac": achieved / 2500.0,
+                         "frac_at_sampled_clock": (achieved / (2500.0 * clocks["sclk_mhz"] / 2400.0)) if clocks else None,
+                         "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g_by / n_g,
                          "kernel": "imh::gemm_* (Linear + implicit-GEMM conv3x3 family: gemm_kernel, gemm_dual, gemm_ring, gemm_kg2, gemm_pq, gemm_ws, conv_halo)",
                          "launches_per_step": n_g, "avg_launch_us": g_ms / n_g * 1e3,
@@ -601,6 +634,16 @@ def main():
                 "bound": "mfma", "achieved": x_fl / (x_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": x_fl / (x_ms * 1e-3) / 1e12 / 2500.0, "kernel": "imh::xattn_kernel (all 70 cross-attention layers: to_q + SDPA fused)",
                 "launches_per_step": n_x, "avg_launch_us": x_ms / n_x * 1e3, "algorithmic_tflop_per_step": x_fl / 1e12}
+        co = [(t[3], m) for t, m in zip(rec.tags, ms) if t[2] == "cross.to_out"]
+        if co:
+            c_fl, c_ms = sum(f for f, _ in co), sum(m for _, m in co)
+            res["roofline_cross_to_out"] = {
+                "bound": "mfma", "achieved": c_fl / (c_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": c_fl / (c_ms * 1e-3) / 1e12 / 2500.0,
+                "kernel": "imh::gemm_ws_kernel 64 x 160 (to_out + bias + residual of the 70 cross-attention layers: the second launch of an "
+                          "IPAttnProcessor2_0 call, attention_processor.py:453)",
+                "launches_per_step": len(co), "avg_launch_us": c_ms / len(co) * 1e3,
+                "note": "2048 x 1280 x 1280 (60 layers) / 8192 x 640 x 640 (10): one round of 256 workgroups whose K loop streams 573 KB per CU "
+                        "through the L2 -> LDS path (tools/micro/lds_port.hip: the loop runs at that stream's rate, 39 B / clk / CU)"}
         if world == 1 and a.stacked > 1:
             try:
                 res["roofline_ip_attn_cfg4"] = ip_attn_cfg4(device, dtype)

@@ -384,8 +384,15 @@ int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipS
         }
         if ((p->flags & GF_GEGLU) && (p->N & 15)) { set_error("geglu: N must be a multiple of 16"); return IMH_ERR_SHAPE; }
         if (p->rowadd && p->rows_per_batch <= 0) { set_error("gemm_dual: rowadd needs rows_per_batch"); return IMH_ERR_ARG; }
+        // fields only the single-problem launcher implements (gemm_launch validates and normalises them): refuse them here instead of
+        // letting a tile kernel read Cin1 / Yt unchecked
+        if (p->Yt || p->gn_tab || p->X2 || p->gn_out || p->ln_stats_out || p->splits > 1) {
+            set_error("gemm_dual: Yt / gn_tab / X2 / gn_out / ln_stats_out / split-K are single-problem (imh_gemm) features");
+            return IMH_ERR_ARG;
+        }
     }
     a.splits = b.splits = 1;
+    a.Cin1 = a.K; b.Cin1 = b.K;                 // (one token source each)
     const int lnf = GF_LN_ROW | GF_LN_COL;
     if (((a.flags | b.flags) & lnf) && !((a.flags & lnf) == GF_LN_ROW && (b.flags & lnf) == GF_LN_COL)) {
         set_error("gemm_dual: folded LayerNorm needs problem a in row form and problem b in column form");

@@ -102,7 +102,8 @@ __device__ __forceinline__ float silu_f(float x) {
 }
 // erf-GELU (diffusers GEGLU / nn.GELU(): 0.5 x (1 + erf(x / sqrt 2))) WITHOUT transcendentals: erf(x / sqrt 2) = x Q(x^2) on
 // |x| <= 3.3 sqrt 2 (clamped; 1 - erf(3.3) = 3e-6), Q a degree-10 minimax fit evaluated by Horner in u = 2 x^2 / xmax^2 - 1 (in [-1, 1]:
-// well conditioned in fp32).  |erf error| <= 5.1e-6, |GELU error| <= 1.2e-5 over all x in fp32 -- two orders below bf16 / fp16
+// well conditioned in fp32).  |erf error| <= 5.1e-6, |GELU error| <= 1.2e-5 over all x in fp32 (beyond the fit range erf is set to +-1
+// exactly, so GELU(x) is exactly x or 0 there) -- two orders below bf16 / fp16
 // output resolution.  Only FMAs, so two gates go through one v_pk_fma_f32 stream (gelu2): ~8.5 VALU issues per gate instead of
 // 14 + v_rcp + v_exp (Abramowitz-Stegun 7.1.26, rounds 1-3) -- the GEGLU epilogue of ff.net.0 evaluates 160 gates per lane per tile.
 // (fit: tools/fit_gelu_poly.py)
@@ -132,7 +133,10 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 #pragma unroll
     for (int i = 1; i <= 10; ++i) q = __builtin_fmaf(q, u, gelu_coef(i));
     const float h = 0.5f * x;
-    return __builtin_fmaf(h, xc * q, h);
+    // beyond the fit range erf is exactly +-1 (a clamped fit value of 1 - 3e-6 would leave x * 1.5e-6 instead of 0 for x << 0: an error
+    // that grows with |x|)
+    const float e = __builtin_fabsf(x) >= GELU_XMAX ? __builtin_copysignf(1.0f, x) : xc * q;
+    return __builtin_fmaf(h, e, h);
 }
 // two gates at once on packed fp32 (plain even-aligned register pairs, broadcast constants: no op_sel low-lane selects)
 __device__ __forceinline__ f32x2v gelu2(f32x2v x) {
@@ -146,7 +150,10 @@ __device__ __forceinline__ f32x2v gelu2(f32x2v x) {
     for (int i = 1; i <= 10; ++i) { const f32x2v c = {gelu_coef(i), gelu_coef(i)}; q = __builtin_elementwise_fma(q, u, c); }
     const f32x2v hf = {0.5f, 0.5f};
     const f32x2v h = x * hf;
-    return __builtin_elementwise_fma(h, xc * q, h);
+    f32x2v e = xc * q;
+    e[0] = __builtin_fabsf(x[0]) >= GELU_XMAX ? __builtin_copysignf(1.0f, x[0]) : e[0];      // exactly +-1 beyond the fit range (see gelu_erf_f)
+    e[1] = __builtin_fabsf(x[1]) >= GELU_XMAX ? __builtin_copysignf(1.0f, x[1]) : e[1];
+    return __builtin_elementwise_fma(h, e, h);
 }
 // GEGLU over a lane's NV consecutive pre-activation columns, interleaved in QUADS (value_2k, value_2k+1, gate_2k, gate_2k+1) -- the two
 // gates of a quad sit in one even-aligned accumulator pair: o[2k], o[2k+1] = v[4k], v[4k+1] * gelu(v[4k+2], v[4k+3])

@@ -224,6 +224,9 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     const int b = hb / HP, h0 = (hb - b * HP) * 2;
     const int q0 = qblk * 128;
     const int nkt = xp.C / 64;
+#if XA_TIMING
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // staging map: instruction rb (0..31) fills tile rows rb*8 .. rb*8+7; rows 0..127 = tokens, 128..255 = weight rows
     auto src_of = [&](int rb) -> const unsigned char* {
@@ -257,7 +260,9 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
             __builtin_amdgcn_s_barrier();                  // tile i + 1 has landed, tile i has been read
             if (++slot == S) slot = 0;
         }
+#if !XA_TIMING
         tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid - 512, 64 * NP);
+#endif
         return;
     }
 
@@ -348,6 +353,9 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
         __builtin_amdgcn_s_barrier();      // every wave is done with the projection stages: the K / V^T rings may reuse them
     }
 
+#if XA_TIMING
+    const unsigned long long ts_proj = __builtin_amdgcn_s_memrealtime();
+#endif
     v8 qf[4];
     {
         float mean = 0.f, rstd = 1.f;
@@ -415,8 +423,19 @@ __global__ __launch_bounds__(64 * (8 + NP), 1) void xattn2_kernel(const XAttnPar
     } else {
         attn_core<T, 4, NPASS>(p, gs, qf, b, h, qg, lane, item, fin);
     }
+#if XA_TIMING
+    const unsigned long long ts_keys = __builtin_amdgcn_s_memrealtime();
+#endif
     attn_store<T, 4>(p, gs, fin, b, h, q0, qg, lane);
+#if XA_TIMING
+    if (tid == 0 && p.pf_ptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)item * 4;
+        dbg[0] = ts_entry; dbg[1] = ts_proj; dbg[2] = ts_keys; dbg[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#else
     if (NP == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 512);
+#endif
 }
 
 template <typename T, int NPASS, bool LNQ, int NP, int S, bool RES>

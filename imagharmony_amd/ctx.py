@@ -118,7 +118,10 @@ class Ctx:
 
     def workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=self.device)
+            # (a recording context keeps one generous slab for the whole plan; an eager context -- one per conditioning-module call --
+            # takes what the launch needs: 64 MB per call was a device allocation per Resampler pass)
+            floor = (64 << 20) if self.record else (1 << 20)
+            self._ws = torch.empty(max((int(nbytes) + (1 << 20) - 1) >> 20 << 20, floor), dtype=torch.uint8, device=self.device)
             if self.record:
                 self.keep.append(self._ws)
         return self._ws
@@ -353,6 +356,9 @@ class Ctx:
         """Two independent GEMMs (dicts of gemm() keyword arguments incl. x, w) in one launch.  The folded-LayerNorm pair
         (g1 row form on x, g2 column form with the same token rows as its w) shares one statistics tensor; when the caller has
         none, a row-statistics launch over the token rows supplies it."""
+        for g in (g1, g2):
+            if g.get("x2") is not None or g.get("yt") is not None or g.get("gn_out") is not None or g.get("stats_out"):
+                raise L.ImhError(f"{descr}: x2 / yt / gn_out / stats_out are single-problem (Ctx.gemm) features")
         own = None
         l1, l2 = g1.get("ln"), g2.get("ln")
         if l1 is not None and (len(l1) < 4 or l1[3] is None):

@@ -14,6 +14,9 @@ from . import lib as L
 from .ctx import Ctx
 from .unet import StepState
 
+# XCD cell policy measured once per (device, UNet batch, latent size, dtype) and process: every engine (and fork) of that shape reuses it
+_XCD_PICK = {}
+
 
 class DenoiseEngine:
     def __init__(self, unet, device, dtype=torch.bfloat16, use_graph=True):
@@ -31,6 +34,9 @@ class DenoiseEngine:
         # (IMH_XCD_AUTOTUNE=0: model only)
         self.xcd_candidates = (0, 3, 2, 13) if os.environ.get("IMH_XCD_AUTOTUNE", "1") != "0" else (0,)
         self.xcd_cells = None
+        self._is_fork = False
+        self._plans = {}         # recorded plans by schedule key (two-stage PNS alternates a preview and a final schedule per image)
+        self._sched_key = None
 
     # -- conditioning (once per image / per PNS run; shared by every candidate seed) --
     @torch.no_grad()
@@ -47,6 +53,7 @@ class DenoiseEngine:
             raise ValueError("cfg_role must be None, 0 (unconditional half) or 1 (conditional half)")
         if cfg_role != getattr(self, "cfg_role", None):
             self.plan = None
+        self._plans = {}                          # every recorded plan points into the previous conditioning's caches
         self.cfg_role = cfg_role
         self.do_cfg = guidance_scale > 1.0                                   # custom_pipelines.py:223
         self.guidance = float(guidance_scale)
@@ -80,9 +87,24 @@ class DenoiseEngine:
     # -- schedule tables --
     def set_schedule(self, scheduler, num_inference_steps, control_guidance_start=0.0, control_guidance_end=1.0,
                      denoising_end=None):
+        st, dev = self.st, self.device
+        from .attention_processor import IPAttnProcessor2_0
+        base = next((p.scale for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor2_0)), 1.0)
+        key = (type(scheduler).__name__, int(getattr(scheduler, "num_train_timesteps", 1000)), int(num_inference_steps), float(control_guidance_start), float(control_guidance_end), denoising_end, float(base))
+        hit = self._plans.get(key)
+        if hit is not None:
+            # a schedule this engine has run under this conditioning: its tables, time-embedding rows and recorded plan are still there
+            # (the plan's launches point at them), so a preview / final alternation re-records nothing
+            scheduler.set_timesteps(num_inference_steps)
+            for k in ("t_table", "coef_tab", "in_scale_tab", "ip_scale_tab", "temb_table"):
+                setattr(st, k, hit["st"][k])
+            self.steps, self.init_noise_sigma = hit["steps"], hit["init_noise_sigma"]
+            self.plan, self.noise_pred, self._temb_ctx = hit["plan"], hit["noise_pred"], hit["temb_ctx"]
+            self.plan_tail, self.np_full = hit.get("plan_tail"), hit.get("np_full")
+            self._sched_key = key
+            return
         scheduler.set_timesteps(num_inference_steps)
         tab = scheduler.tables()
-        st, dev = self.st, self.device
         n = num_inference_steps
         if denoising_end is not None and isinstance(denoising_end, float) and 0 < denoising_end < 1:
             # custom_pipelines.py:303-311: stop once t falls below the cut-off; the gating window below then counts
@@ -91,12 +113,7 @@ class DenoiseEngine:
             n = int((tab["timesteps"] >= cutoff).sum().item())
         st.t_table = tab["timesteps"].to(dev)
         st.coef_tab = tab["coef"].contiguous().to(dev)
-        new_in = tab["in_scale"].to(dev) if tab["in_scale"] is not None else None
-        if (new_in is None) != (st.in_scale_tab is None):
-            self.plan = None
-        st.in_scale_tab = new_in
-        from .attention_processor import IPAttnProcessor2_0
-        base = next((p.scale for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor2_0)), 1.0)
+        st.in_scale_tab = tab["in_scale"].to(dev) if tab["in_scale"] is not None else None
         gate = [0.0 if (i / n < control_guidance_start) or ((i + 1) / n > control_guidance_end) else float(base)
                 for i in range(n)]                                           # custom_pipelines.py:319-329
         st.ip_scale_tab = torch.tensor(gate, dtype=torch.float32, device=dev)
@@ -105,12 +122,14 @@ class DenoiseEngine:
         self.steps = n
         self.init_noise_sigma = float(tab["init_noise_sigma"])
         self.plan = None                         # table pointers changed
+        self._sched_key = key
 
     def fork(self):
         """A second engine on the SAME weights and the SAME conditioning (K/V caches, aug_emb) with its own latents,
         step counter, activation buffers and plan: lets several PNS candidates be in flight on one GPU (one HIP
         stream each), so that kernels of independent candidates fill the CUs a batch-1 kernel leaves idle."""
         e = DenoiseEngine(self.unet, self.device, self.dtype, self.use_graph)
+        e._is_fork = True                        # never tunes: it may record while its parent is running on another stream
         for k in ("do_cfg", "guidance", "guidance_rescale", "S", "H", "W", "T_total", "steps", "init_noise_sigma", "_cond_ctx", "cfg_role",
                   "xcd_candidates", "xcd_cells"):
             setattr(e, k, getattr(self, k))
@@ -131,7 +150,12 @@ class DenoiseEngine:
         self.unet.precompute_temb(self._temb_ctx, st, st.t_table)
         split = self.do_cfg and getattr(self, "cfg_role", None) is not None
         if not split and self.use_graph and len(self.xcd_candidates) > 1 and self.xcd_cells is None:
-            self.xcd_cells = self._pick_xcd_cells()
+            pk = (self.device.index or 0, self.S, self.H, self.W, str(self.dtype), bool(self.do_cfg))
+            if pk not in _XCD_PICK and not self._is_fork:
+                _XCD_PICK[pk] = self._pick_xcd_cells()
+            self.xcd_cells = _XCD_PICK[pk][0] if pk in _XCD_PICK else 0
+            if pk in _XCD_PICK:
+                self.xcd_times_ms = _XCD_PICK[pk][1]
         rec = Ctx(self.device, self.dtype, record=True)
         rec.xcd_cells = self.xcd_cells or 0
         out = self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg and not split)
@@ -154,6 +178,7 @@ class DenoiseEngine:
             if self.use_graph:
                 tail.capture()
             self.plan_tail = tail
+            self._remember_plan()
             return
         rec.tag = 70
         fac = None
@@ -168,6 +193,18 @@ class DenoiseEngine:
             rec.capture()
         self.plan = rec
         self.noise_pred = out
+        self._remember_plan()
+
+    def _remember_plan(self):
+        if self._sched_key is None:
+            return
+        st = self.st
+        self._plans[self._sched_key] = dict(
+            st={k: getattr(st, k, None) for k in ("t_table", "coef_tab", "in_scale_tab", "ip_scale_tab", "temb_table")},
+            steps=self.steps, init_noise_sigma=self.init_noise_sigma, plan=self.plan, noise_pred=self.noise_pred,
+            temb_ctx=self._temb_ctx, plan_tail=getattr(self, "plan_tail", None), np_full=getattr(self, "np_full", None))
+        while len(self._plans) > 3:              # (each plan keeps ~2 GB of activation buffers alive at 1024^2)
+            self._plans.pop(next(iter(self._plans)))
 
     def _pick_xcd_cells(self):
         """Which XCD cell shape this box prefers for the GEMM / conv launches of the forward (imh_gemm_args.xcd): the byte-count model
@@ -182,18 +219,19 @@ class DenoiseEngine:
             rec.xcd_cells = cells
             self.unet.emit_forward(rec, st, self.S, self.H, self.W, cfg_dup=self.do_cfg)
             rec.capture()
-            best = None
-            for i in range(4):
+            ts = []
+            for i in range(11):
                 self.eager.ew(L.EW_STEP_SET, st.step, i=(0, 1, 0, 0, 0, 0), descr="step=0")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); rec.replay(); e1.record()
                 torch.cuda.synchronize(self.device)
                 if i:                                      # the first replay is the warm-up
-                    best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
-            times[cells] = best
+                    ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            times[cells] = ts[len(ts) // 2]                # median of ten: the candidates are 1-2 % apart
             del rec
         self.xcd_times_ms = times
-        return min(times, key=times.get)
+        return min(times, key=times.get), times
 
     @torch.no_grad()
     def denoise_cfg_split(self, latents, exchange):

@@ -90,6 +90,16 @@ class IPAdapter:
         if ip_ckpt is not None:
             self.load_ip_adapter()
 
+    def _g(self, module):
+        """the conditioning module as a replayed hipGraph (modules.Graphed): get_image_embeds runs the 0.8 ms replay, not an eager pass
+        of ~45 launches; CPU tensors (the host-logic tests) go straight through"""
+        from .modules import Graphed
+        cache = self.__dict__.setdefault("_graphed", {})
+        w = cache.get(id(module))
+        if w is None or w.module is not module:
+            w = cache[id(module)] = Graphed(module)
+        return w
+
     def init_proj(self):                                                  # ip_adapter.py:91-97
         return ImageProjModel(cross_attention_dim=self.pipe.unet.config.cross_attention_dim,
                               clip_embeddings_dim=self.clip_embeddings_dim,
@@ -129,14 +139,14 @@ class IPAdapter:
         clip_image_embeds = self._clip_embeds(pil_image, clip_image_embeds)
         if extra_prompt_embeds is not None and self.number_class_crossattention is not None:
             extra = extra_prompt_embeds.to(self.device, self.dtype)
-            clip_image_embeds = clip_image_embeds + self.number_class_crossattention(extra, clip_image_embeds)   # :170-173
+            clip_image_embeds = clip_image_embeds + self._g(self.number_class_crossattention)(extra, clip_image_embeds)   # :170-173
         return clip_image_embeds
 
     @torch.inference_mode()
     def get_image_embeds(self, pil_image=None, clip_image_embeds=None, extra_prompt_embeds=None):   # ip_adapter.py:158-177
         clip_image_embeds = self.fused_clip_embeds(pil_image, clip_image_embeds, extra_prompt_embeds)
-        image_prompt_embeds = self.image_proj_model(clip_image_embeds)
-        uncond_image_prompt_embeds = self.image_proj_model(torch.zeros_like(clip_image_embeds))
+        image_prompt_embeds = self._g(self.image_proj_model)(clip_image_embeds)
+        uncond_image_prompt_embeds = self._g(self.image_proj_model)(torch.zeros_like(clip_image_embeds))
         return image_prompt_embeds, uncond_image_prompt_embeds
 
     def set_scale(self, scale):                                           # ip_adapter.py:179-182
@@ -250,8 +260,8 @@ class IPAdapterXL(IPAdapter):
             extra_prompt_embeds = pipe.encode_prompt(extra_text, num_images_per_prompt=1, do_classifier_free_guidance=True,
                                                      negative_prompt=negative_prompt)[0]
         fused = self.fused_clip_embeds(pil_image, clip_image_embeds, extra_prompt_embeds)
-        ipe = self.image_proj_model(fused)
-        uipe = self.image_proj_model(torch.zeros_like(fused))
+        ipe = self._g(self.image_proj_model)(fused)
+        uipe = self._g(self.image_proj_model)(torch.zeros_like(fused))
         if prompt_embeds is None:
             prompt_embeds = pipe.encode_prompt(prompt, num_images_per_prompt=1, do_classifier_free_guidance=True,
                                                negative_prompt=negative_prompt)
@@ -326,7 +336,7 @@ class IPAdapterPlus(IPAdapter):
             raise NotImplementedError("pass uncond_clip_image_embeds (CLIP hidden states of an all-zero image)")
         c = clip_image_embeds.to(self.device, self.dtype)
         u = uncond_clip_image_embeds.to(self.device, self.dtype)
-        return self.image_proj_model(c), self.image_proj_model(u)
+        return self._g(self.image_proj_model)(c), self._g(self.image_proj_model)(u)
 
 
 class IPAdapterFull(IPAdapterPlus):
@@ -356,7 +366,7 @@ class IPAdapterPlusXL(IPAdapter):
             uncond_clip_hidden_states = self.image_encoder(torch.zeros_like(px), output_hidden_states=True).hidden_states[-2]
         c = clip_hidden_states.to(self.device, self.dtype)
         u = uncond_clip_hidden_states.to(self.device, self.dtype)
-        return self.image_proj_model(c), self.image_proj_model(u)
+        return self._g(self.image_proj_model)(c), self._g(self.image_proj_model)(u)
 
     def generate(self, pil_image=None, prompt=None, negative_prompt=None, scale=1.0, num_samples=4, seed=None,
                  num_inference_steps=30, clip_hidden_states=None, uncond_clip_hidden_states=None, prompt_embeds=None,

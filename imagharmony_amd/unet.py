@@ -390,7 +390,11 @@ class ResnetBlock2D(nn.Module):
             else:
                 sc = ctx.gemm((xc if xc is not None else x).view(M, Cin), wsc, bias=bsc, descr="res.shortcut")
         else:
-            sc = x.view(M, Cin)
+            # identity shortcut: the residual is the block's INPUT -- with a skip connection that is the concatenated tensor (no SDXL up
+            # block gets here: Cin = C1 + Cskip != Cout always has a conv_shortcut)
+            if sk is not None and xc is None:
+                xc = ctx.concat(x, sk, descr="skip.concat")
+            sc = (xc if xc is not None else x).view(M, Cin)
         if GN_FUSE and ctx.conv_fuses_gn(M, Cout, 9 * Cout):
             out = ctx.conv3x3(hf.t, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2", gn_groups=want,
                               gn=(tab2, True))

@@ -126,6 +126,13 @@ def test_gemm_epilogues(L, dtype):
     assert_close(ctx.gemm(x, w, bias=b, residual=r), ref + b.float() + r.float(), dtype, "bias+residual")
     assert_close(ctx.gemm(x, w, bias=b, flags=L.GF_ACT_SILU), F.silu(ref + b.float()), dtype, "silu")
     assert_close(ctx.gemm(x, w, flags=L.GF_ACT_GELU), F.gelu(ref), dtype, "gelu")
+    # large-magnitude pre-activations (beyond the polynomial's fit range |x| <= 4.67): GELU is exactly x or 0 there, not x * (1 +- 3e-6)
+    big = ctx.gemm((x * 64).to(dtype), w, flags=L.GF_ACT_GELU | L.GF_OUT_F32).float()
+    ref_big = (x * 64).to(dtype).float() @ w.float().t()
+    far = ref_big.abs() > 6.0
+    assert far.float().mean() > 0.5
+    assert torch.equal(big[far & (ref_big < 0)], torch.zeros_like(big[far & (ref_big < 0)]))
+    assert (big[far & (ref_big > 0)] - ref_big[far & (ref_big > 0)]).abs().max() <= 1e-4 * ref_big.abs().max()
     # rowadd: 3 batches of 64 rows, row stride larger than N (stacked time_emb_proj layout)
     ra_full = rnd(3, N + 64, dtype=dtype, seed=5)
     ra = ra_full[:, 32:32 + N]

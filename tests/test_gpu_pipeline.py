@@ -153,6 +153,21 @@ def test_engine_picks_an_xcd_cell_shape_and_every_shape_gives_the_same_bits():
             assert e.xcd_cells in e.xcd_candidates and set(e.xcd_times_ms) == set(e.xcd_candidates)
             assert all(t > 0 for t in e.xcd_times_ms.values())
             assert e.fork().xcd_cells == e.xcd_cells           # in-flight candidates reuse the pick
+            # ... and so does every later engine of this shape in the process: the pick is measured once per (device, batch, size, dtype)
+            e2 = DenoiseEngine(hu, DEV, torch.bfloat16, use_graph=True)
+            e2._pick_xcd_cells = lambda: (_ for _ in ()).throw(AssertionError("the XCD policy was measured twice"))
+            e2.set_conditioning(pe.to(DEV), ne.to(DEV), po.to(DEV), no.to(DEV), hw * 8, hw * 8, guidance_scale=5.0)
+            e2.set_schedule(hs.DDIMScheduler(), steps)
+            assert torch.equal(e2.denoise(lat).float().cpu(), outs[None]) and e2.xcd_cells == e.xcd_cells
+            # alternating two schedules (two-stage PNS: preview / final) re-records nothing the second time round
+            p_short = e2.plan
+            e2.set_schedule(hs.DDIMScheduler(), steps + 1)
+            long1 = e2.denoise(lat).float().cpu().clone()
+            p_long = e2.plan
+            e2.set_schedule(hs.DDIMScheduler(), steps)
+            assert e2.plan is p_short and torch.equal(e2.denoise(lat).float().cpu(), outs[None])
+            e2.set_schedule(hs.DDIMScheduler(), steps + 1)
+            assert e2.plan is p_long and torch.equal(e2.denoise(lat).float().cpu(), long1)
     for cells, o in outs.items():
         assert torch.equal(o, outs[0]), f"xcd cells {cells}"
 

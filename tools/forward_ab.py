@@ -55,6 +55,8 @@ CONFIGS = collections.OrderedDict([
     # round 5: the same convolutions on the 8 x 16-patch x 80-cout form whose wave pairs split the K range (conv_halo.hip KS)
     ("conv32_ks80", dict(tuning={f"2048,1280,{k},1": [7128, 80, 1] for k in (5760, 11520, 17280, 23040)})),
     ("conv32_ws", dict(tuning={f"2048,1280,{k},1": [2464, 160, 1] for k in (5760, 11520, 17280, 23040)})),
+    ("conv64_ks80", dict(tuning={f"8192,640,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
+    ("conv128_ks80", dict(tuning={f"32768,320,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640)})),
     ("halo_svc", dict(halo=3)),                       # imh_debug_set key 5 = 3: four halo waves for every LDS-halo conv, as SERVICE waves (they also run the weight ring)
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),

@@ -20,5 +20,11 @@ unset IMH_XCD_AUTOTUNE
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS -d $out/${tag}_s1 -o s -- python tools/pmc_gemm.py > /dev/null 2>&1; echo "sq1 rc=$?"
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d $out/${tag}_s2 -o s -- python tools/pmc_gemm.py > /dev/null 2>&1; echo "sq2 rc=$?"
 python tools/pmc_sq_summary.py $(find $out/${tag}_s1 -name "*results.db" | head -1) $(find $out/${tag}_s2 -name "*results.db" | head -1) > $out/${tag}_pmc_sq_gemm_attn.md
-rm -rf $out/${tag}_kt $out/${tag}_pf $out/${tag}_pw $out/${tag}_s1 $out/${tag}_s2
+# the north-star call on its own (xattn_kernel + the to_out launch that reads its output), batch 2 and batch 8
+for shp in cfg2 cfg4; do
+timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS -d $out/${tag}_x1$shp -o s -- python tools/pmc_ipattn.py $shp > /dev/null 2>&1; echo "ipattn $shp sq1 rc=$?"
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d $out/${tag}_x2$shp -o s -- python tools/pmc_ipattn.py $shp > /dev/null 2>&1; echo "ipattn $shp sq2 rc=$?"
+python tools/pmc_sq_summary.py $(find $out/${tag}_x1$shp -name "*results.db" | head -1) $(find $out/${tag}_x2$shp -name "*results.db" | head -1) | sed "s/^# SQ counters per launch.*/# SQ counters per launch of the north-star IP-attention call, $shp (tools\/pmc_ipattn.py: xattn_kernel + to_out gemm_ws 64x160)/" > $out/${tag}_pmc_sq_ipattn_$shp.md
+done
+rm -rf $out/${tag}_kt $out/${tag}_pf $out/${tag}_pw $out/${tag}_s1 $out/${tag}_s2 $out/${tag}_x1cfg2 $out/${tag}_x2cfg2 $out/${tag}_x1cfg4 $out/${tag}_x2cfg4
 ls -la $out | grep ${tag}_

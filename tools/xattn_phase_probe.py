@@ -20,8 +20,11 @@ from imagharmony_amd.ctx import Ctx
 DEV = "cuda:0"; dtype = torch.bfloat16
 ctx = Ctx(DEV, dtype)
 q = lambda t, f: float(t.kthvalue(max(1, int(f * t.numel())))[0])
-for (name, B, H, Lq, T) in [("cfg2 text only", 2, 20, 1024, 0), ("cfg2 + 4 ip tokens", 2, 20, 1024, 4), ("cfg4 batch 8 + 16 ip", 8, 20, 1024, 16),
-                            ("C = 640, L = 4096", 2, 10, 4096, 0)]:
+for (name, B, H, Lq, T, mode) in [("cfg2 text only", 2, 20, 1024, 0, 1), ("cfg2 + 4 ip tokens", 2, 20, 1024, 4, 1), ("cfg4 batch 8 + 16 ip", 8, 20, 1024, 16, 1),
+                                  ("C = 640, L = 4096", 2, 10, 4096, 0, 1),
+                                  ("cfg2 text only, 2 heads np2", 2, 20, 1024, 0, 3), ("cfg2 text only, 2 heads np4", 2, 20, 1024, 0, 4),
+                                  ("cfg2 + 4 ip, 2 heads np4", 2, 20, 1024, 4, 4), ("cfg4 batch 8 + 16 ip, 2 heads np4", 8, 20, 1024, 16, 4)]:
+    ctx.lib.imh_debug_set(3, mode)
     C_ = H * 64
     x = torch.randn(B * Lq, C_, device=DEV).to(dtype); wq = (torch.randn(C_, C_, device=DEV) * C_ ** -0.5).to(dtype)
     k = torch.randn(B * 128, C_, device=DEV).to(dtype); vt = torch.randn(C_, B * 128, device=DEV).to(dtype)
@@ -31,7 +34,7 @@ for (name, B, H, Lq, T) in [("cfg2 text only", 2, 20, 1024, 0), ("cfg2 + 4 ip to
     kw = dict(k2=k2, vt2=vt2, Lk2=T, Lk2_pad=64, ldk2=C_, ldvt2=B * 64, scale2=1.0) if T else {}
     rec.cross_attention(x, wq, k, vt, out, B, H, Lq, 77, 128, C_, B * 128, 0.125, **kw)
     a = rec._ops[-1][1]
-    items = (Lq // 128) * H * B
+    items = (Lq // 128) * (H if mode == 1 else H // 2) * B
     dbg = torch.zeros(4 * items + 8, dtype=torch.int64, device=DEV)
     a.pf_ptr, a.pf_bytes = dbg.data_ptr(), 0
     for _ in range(3):
