@@ -14,6 +14,13 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # IMH_KERNEL (csrc/imh_common.h) carries __attribute__((target("no-packed-fp32-ops"))) for the gemm.hip kernels; the
 # attribute only means something to the device pass, the host pass says "attribute ignored" -> -Wno-ignored-attributes.
 CFLAGS.append("-Wno-ignored-attributes")
+# IMH_EXPERIMENTAL=1: also compile the measured-but-not-selected kernel variants (csrc/imh_common.h IMH_EXP_ONLY; the library answers
+# imh_debug_set(1, 0) with 1).  The default library holds what tuning.json and the default modes reach.
+EXPERIMENTAL = os.environ.get("IMH_EXPERIMENTAL") == "1"
+if EXPERIMENTAL:      # a second library next to the tools (use it with IMH_LIB_PATH=tools/tmp_libs/libimh_hip_experimental.so); the in-tree one stays the default build
+    CFLAGS.append("-DIMH_EXPERIMENTAL")
+    OBJ = os.path.join(HERE, "..", "tools", "tmp_libs", "_obj_experimental")
+    OUT = os.path.join(HERE, "..", "tools", "tmp_libs", "libimh_hip_experimental.so")
 
 
 def sources():

@@ -21,6 +21,11 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int experimental_refused(const char* what) {
+    set_error("%s is compiled only with -DIMH_EXPERIMENTAL (IMH_EXPERIMENTAL=1 python -m imagharmony_amd.build): measured, not selected by any "
+              "tuning.json entry or default mode", what);
+    return IMH_ERR_ARG;
+}
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -223,6 +228,13 @@ extern "C" {
 int imh_abi_version(void) { return IMH_ABI_VERSION; }
 int imh_debug_set(int key, int value) {
     if (key == 0) { g_attn_force_nw = value; return IMH_OK; }
+    if (key == 1) {                               // query: was this library built with -DIMH_EXPERIMENTAL?
+#ifdef IMH_EXPERIMENTAL
+        return 1;
+#else
+        return 0;
+#endif
+    }
     if (key == 2) { g_xcd_mode = value; return IMH_OK; }
     if (key == 3) { g_xattn_mode = value; return IMH_OK; }
     if (key == 4) { g_attn_mode = value; return IMH_OK; }

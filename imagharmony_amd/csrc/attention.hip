@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
 // query groups; 128 registers and 64 KB of LDS -> two workgroups = four waves per SIMD on a CU.  Q fragments come straight from
 // memory (lane (q, hi) reads its row's four 16-B pieces: 32 lines per instruction, once per workgroup, in flight beside the
 // first K / V^T tile) -- no Q staging tile, no extra barrier.
+#ifdef IMH_EXPERIMENTAL
 template <typename T>
 __global__ __launch_bounds__(512, 4) void attn_ks_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 v8;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(512, 4) void attn_ks_kernel(const AttnParams p) {
     if (g == 0) attn_store<T, 4>(p, smem + 4 * 34 * 64 * 4, fin, b, h, q0, qg, lane);
     else tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid - 256, 256);
 }
+#endif
 
 // ---- small generic attention (any head dims <= 128, short sequences): one workgroup per (batch, head).
 // Used once per image by HarmonyAttention's Cross_Attention (head_dim 40, value_dim 64, 8 queries x 77 keys;
@@ -335,6 +337,9 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
     // (auto keeps the software-pipelined kernel: the two measure the same in the forward, 38.4 vs 38.7 us per launch,
     // profiles/r04_forward_ab_attn.json)
     if (!p.K2 && p.Lk % (2 * ATT_KV) == 0 && p.Lk >= 4 * ATT_KV && (g_attn_mode == 5 || g_attn_mode == 6)) {
+#ifndef IMH_EXPERIMENTAL
+        return experimental_refused("the key-split attention kernel (imh_debug_set(4, 5 | 6))");
+#else
         const int lds = 2 * 2 * 2 * ATT_TILE_BYTES;
         const int items128 = ((p.Lq + 127) / 128) * p.H * p.B;
         dim3 grid2(8 * ((items128 + 7) / 8));
@@ -345,6 +350,7 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
         else { static DynLdsOnce once; once.ensure((const void*)attn_ks_kernel<f16_t>, lds);
                hipLaunchKernelGGL((attn_ks_kernel<f16_t>), grid2, dim3(512), lds, stream, q); }
         return check_launch("attn_ks_kernel");
+#endif
     }
     if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || g_attn_mode == 3 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
         const int lds = ATT_PIPE_STAGES * 2 * ATT_TILE_BYTES;

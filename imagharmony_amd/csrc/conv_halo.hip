@@ -478,8 +478,11 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
 #define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) IMH_CH6(TT, FNV, FMV, SV, HV, KSV, KSV)
-    // g_halo_mode == 3 (A/B): the four extra waves of the other forms as service waves too -- measured slower there (four issuing waves
-    // pull 20-40 KB of weights per step more slowly than eight: 22.14 vs 21.86 ms per forward, profiles/r05_forward_ab_halo_svc.json)
+    // default build: every form runs with its four halo waves (the 7128 x 80 form with eight service waves).  -DIMH_EXPERIMENTAL adds the
+    // eight-wave form (g_halo_mode 1), the halo waves of the other forms as service waves (g_halo_mode 3: measured slower there -- four
+    // issuing waves pull 20-40 KB of weights per step more slowly than eight, 22.14 vs 21.86 ms per forward,
+    // profiles/r05_forward_ab_halo_svc.json), the 4 x 16 patch (7564) and the 3- / 4-slot weight rings of the 8 x 16 patch (7328 / 7428)
+#ifdef IMH_EXPERIMENTAL
 #define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) { if (g_halo_mode == 3) IMH_CH6(TT, FNV, FMV, SV, 4, false, true); else IMH_CH6(TT, FNV, FMV, SV, 4, false, false); } \
         else IMH_CH6(TT, FNV, FMV, SV, 0, false, false); } while (0)
 #define IMH_CH(TT) do { \
@@ -488,6 +491,16 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
+#else
+    if (!hw4 || g_halo_mode == 3 || bm == 7564 || bm == 7328 || bm == 7428)
+        return experimental_refused("this LDS-halo conv form (eight-wave / service-wave A-B modes, variants 7564 / 7328 / 7428)");
+#define IMH_CH3(TT, FNV, FMV, SV) IMH_CH6(TT, FNV, FMV, SV, 4, false, false)
+#define IMH_CH(TT) do { \
+        if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
+        else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
+        else if (bn == 320) IMH_CH3(TT, 10, 2, 2); \
+        else IMH_CH3(TT, 5, 2, 2); } while (0)
+#endif
     if (dtype == IMH_DT_BF16) IMH_CH(bf16_t);
     else IMH_CH(f16_t);
 #undef IMH_CH

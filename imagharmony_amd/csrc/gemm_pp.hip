@@ -692,8 +692,12 @@ int gemm_pp_launch(const GemmParams& p, int dtype, int conv, int bm, hipStream_t
     if (dtype != IMH_DT_BF16 && dtype != IMH_DT_F16) { set_error("gemm_pp: unknown dtype %d", dtype); return IMH_ERR_DTYPE; }
     const bool bf = dtype == IMH_DT_BF16;
     if (bm == 9256) {
+#ifdef IMH_EXPERIMENTAL
         if ((size_t)p.M * p.ldx * 2 >= (1ull << 32) || (size_t)p.N * p.ldw * 2 >= (1ull << 32)) { set_error("gemm_pp: operand too large for 32-bit staging offsets"); return IMH_ERR_SHAPE; }
         return bf ? launch_pr<bf16_t>(p, stream) : launch_pr<f16_t>(p, stream);
+#else
+        return experimental_refused("the 256 x 320 ping-pong variant (9256)");
+#endif
     }
     if (bm == 9128) return bf ? launch_pq<bf16_t>(p, stream) : launch_pq<f16_t>(p, stream);
     return bf ? launch_pp<bf16_t>(p, stream) : launch_pp<f16_t>(p, stream);

@@ -849,6 +849,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), OCC == 1 ? 1 : OCC * (CM * CN 
     gemm_ws_body<T, BM, BN, CM, CN, S, NP, CONV, LN>(p, blockIdx.x, gridDim.x, smem);
 }
 
+#ifdef IMH_EXPERIMENTAL
 // Self-attention's projections in ONE wave-specialised launch, LayerNorm statistics handed over (imh_lnstats.h):
 //   a: [Q|K] = LN(x) [Wq;Wk]^T   row form, 128 x 160 tiles (M = 2048 x N = 2560 -> 256 tiles)
 //   b: V^T   = Wv LN(x)^T        column form + V^T key permutation, 128 x 128 tiles (1280 x 2048 -> 160 tiles)
@@ -880,6 +881,9 @@ int gemm_ws_dual_launch(const GemmParams& a, const GemmParams& b, int dtype, hip
     set_error("gemm_ws_dual: unknown dtype %d", dtype);
     return IMH_ERR_DTYPE;
 }
+#else
+int gemm_ws_dual_launch(const GemmParams&, const GemmParams&, int, hipStream_t) { return experimental_refused("the wave-specialised two-problem launch (gemm_dual variant 24128)"); }
+#endif
 
 template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, int LN, int OCC = 1>
 static int launch_ws_ln(const GemmParams& p, hipStream_t stream) {
@@ -934,31 +938,35 @@ template <typename T, bool CONV>
 static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     // small-tile rings (4 waves, several workgroups per CU): the N = 1280 projections are latency-bound in the two-stage
     // kernel (one 16 KB tile in flight per workgroup); 4000 + BM = 4-stage / 3-stage ring, 5000 + BM = 3-stage 64x64
-    if (bm == 4064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 4, CONV>(p, stream);
+    IMH_EXP_ONLY(if (bm == 4064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 4, CONV>(p, stream);)
     if (bm == 5064 && bn == 64) return launch_ring<T, 64, 64, 2, 2, 3, CONV>(p, stream);
-    if (bm == 4064 && bn == 128) return launch_ring<T, 64, 128, 2, 2, 3, CONV>(p, stream);
-    if (bm == 4128 && bn == 64) return launch_ring<T, 128, 64, 2, 2, 3, CONV>(p, stream);
+    IMH_EXP_ONLY(if (bm == 4064 && bn == 128) return launch_ring<T, 64, 128, 2, 2, 3, CONV>(p, stream);)
+    IMH_EXP_ONLY(if (bm == 4128 && bn == 64) return launch_ring<T, 128, 64, 2, 2, 3, CONV>(p, stream);)
     // exact 256-way tilings of the M = 2048 / 8192 Linear layers (every CU gets the same number of equal tiles):
     // 128 x 320 (8 waves, N = 10240 -> 512 tiles) and 64 x 160 (4 waves, N = 1280 -> 256 tiles, deep ring)
-    if (bm == 5256 && bn == 320) return launch_ring<T, 256, 320, 2, 2, 2, CONV>(p, stream);   // 4 waves, 320 accumulator registers
+    IMH_EXP_ONLY(if (bm == 5256 && bn == 320) return launch_ring<T, 256, 320, 2, 2, 2, CONV>(p, stream);)      // 4 waves, 320 accumulator registers
     if (bm == 5258 && bn == 320) return launch_ring<T, 256, 320, 2, 4, 2, CONV>(p, stream);   // 8 waves, 160
-    if (bm == 6128 && bn == 320) return launch_ring<T, 128, 320, 4, 2, 2, CONV>(p, stream);
-    if (bm == 6064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 4, CONV>(p, stream);
-    if (bm == 7064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 3, CONV>(p, stream);
-    if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);
-    if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);
+    IMH_EXP_ONLY(if (bm == 6128 && bn == 320) return launch_ring<T, 128, 320, 4, 2, 2, CONV>(p, stream);)
+    IMH_EXP_ONLY(if (bm == 6064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 4, CONV>(p, stream);)
+    IMH_EXP_ONLY(if (bm == 7064 && bn == 160) return launch_ring<T, 64, 160, 4, 1, 3, CONV>(p, stream);)
+    IMH_EXP_ONLY(if (bm == 256 && bn == 128) return launch_ring<T, 256, 128, 4, 2, 3, CONV>(p, stream);)
+    IMH_EXP_ONLY(if (bm == 256 && bn == 256) return launch_ring<T, 256, 256, 2, 4, 2, CONV>(p, stream);)
     // wave-specialised 64 x 160, 4-stage ring, four consumer waves + two (1464) / four (2464) producer waves
     // (a fifth stage measured no different)
     if (bm == 1464 && bn == 160) return launch_ws<T, 64, 160, 2, 2, 4, 2, CONV>(p, stream);
     if (bm == 2464 && bn == 160) return launch_ws<T, 64, 160, 2, 2, 4, 4, CONV>(p, stream);   // four producer waves
     if (bm == 24128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 4, 4, CONV>(p, stream);  // M = 8192, N = 640: 256 tiles
-    if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 2, 2, 4, 4, CONV>(p, stream);
+    IMH_EXP_ONLY(if (bm == 24128 && bn == 128) return launch_ws<T, 128, 128, 2, 2, 4, 4, CONV>(p, stream);)
     // 128 x 160 with a two-slot ring (74 KB) and 128 registers: TWO workgroups per CU, out of phase with each other
-    if (bm == 22128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 2, 2, CONV, 2>(p, stream);
+    IMH_EXP_ONLY(if (bm == 22128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 2, 2, CONV, 2>(p, stream);)
     // 256 x 160, eight consumer waves (4 x 2, 64 x 80 each) + four producers, 3 stages (156 KB): N = 10240 -> 512 tiles
     if (bm == 23256 && bn == 160) return launch_ws<T, 256, 160, 4, 2, 3, 4, CONV>(p, stream);
-    if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);
+    IMH_EXP_ONLY(if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);)
     if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
+#ifndef IMH_EXPERIMENTAL
+    if (bm == 4064 || bm == 4128 || bm == 5256 || bm == 6128 || bm == 6064 || bm == 7064 || bm == 256 || bm == 22128 || bm == 3128 || (bm == 24128 && bn == 128))
+        return experimental_refused("this gemm_ring / gemm_ws / KG2 variant");
+#endif
     set_error("gemm_ring: unsupported variant %dx%d", bm, bn);
     return IMH_ERR_ARG;
 }

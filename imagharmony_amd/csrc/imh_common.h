@@ -220,4 +220,13 @@ struct DynLdsOnce {
 };
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Kernel variants that no tuning.json entry and no default mode reaches (measured, not selected: profiles/NEGATIVE_RESULTS.md) are compiled
+// only with -DIMH_EXPERIMENTAL (IMH_EXPERIMENTAL=1 python -m imagharmony_amd.build); the default library refuses their codes / modes.
+// imh_debug_set(1, 0) returns 1 from an experimental build, 0 otherwise (the tests filter on it).
+#ifdef IMH_EXPERIMENTAL
+#define IMH_EXP_ONLY(...) __VA_ARGS__
+#else
+#define IMH_EXP_ONLY(...)
+#endif
+int experimental_refused(const char* what);
 }

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 }
 
 
+#ifdef IMH_EXPERIMENTAL
 // ---------------------------------------------------------------------------------------------------------------------
 // Two heads per workgroup.  One workgroup = (batch, head PAIR, 128 queries) = 8 consumer waves (head g = wave >> 2, query
 // group wave & 3) [+ NP producer waves].  Against the one-head kernel above: a 128-query block of X is fetched by H / 2
@@ -468,6 +469,8 @@ static void launch_xattn2_np(const XAttnParams& xp, hipStream_t stream, bool res
     else launch_xattn2_res<T, NP, 4, false>(xp, stream);
 }
 
+#endif      // IMH_EXPERIMENTAL
+
 int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     const AttnParams& p = xp.a;
     if (p.Lk <= 0 || p.Lk_pad % ATT_KV != 0 || p.Lk_pad < p.Lk) {
@@ -507,6 +510,9 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
 #undef IMH_XA
 #undef IMH_XA1
     } else {
+#ifndef IMH_EXPERIMENTAL
+        return experimental_refused("the two-head fused cross-attention kernel (imh_debug_set(3, 2 .. 8))");
+#else
         // modes 2 / 3 / 4: two heads per workgroup with 0 / 2 / 4 producer waves; +4 (6 / 7 / 8): the same without the resident
         // key tiles (A/B)
         const bool res = mode < 6 && p.Lk <= 2 * ATT_KV && (!p.K2 || p.Lk2 <= ATT_KV);
@@ -514,6 +520,7 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
         if (m == 2) { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 0>(xp, stream, res); else launch_xattn2_np<f16_t, 0>(xp, stream, res); }
         else if (m == 4) { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 4>(xp, stream, res); else launch_xattn2_np<f16_t, 4>(xp, stream, res); }
         else { if (dtype == IMH_DT_BF16) launch_xattn2_np<bf16_t, 2>(xp, stream, res); else launch_xattn2_np<f16_t, 2>(xp, stream, res); }
+#endif
     }
     return check_launch("xattn_kernel");
 }

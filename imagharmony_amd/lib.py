@@ -18,6 +18,21 @@ GN_ALL, GN_STATS, GN_TABLE, GN_APPLY = 0, 1, 2, 3
 (EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX,
  EW_ROW_STATS, EW_STEP_ROW) = range(12)
 
+# variant codes / modes that only a -DIMH_EXPERIMENTAL build compiles (csrc/imh_common.h IMH_EXP_ONLY): measured, selected by no
+# tuning.json entry and no default mode.  experimental() asks the loaded library (imh_debug_set(1, 0)).
+EXP_VARIANTS = {(4064, 64), (4064, 128), (4128, 64), (5256, 320), (6128, 320), (6064, 160), (7064, 160), (256, 128), (256, 256), (22128, 160),
+                (3128, 128), (24128, 128), (9256, 320), (7564, 320), (7564, 160), (7328, 160), (7428, 160)}
+
+
+def experimental():
+    return load().imh_debug_set(1, 0) == 1
+
+
+def variant_built(cfg):
+    """cfg = (bm, bn[, splits]): is this tile variant in the loaded library?"""
+    return (int(cfg[0]), int(cfg[1])) not in EXP_VARIANTS or experimental()
+
+
 _i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
 
 

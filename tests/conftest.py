@@ -15,6 +15,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "refshim: needs /root/reference (build container only)")
 
 
+def built(cases):
+    """parametrize lists filtered to what the loaded library compiles: the measured-but-not-selected tile variants and kernel modes exist only
+    in a -DIMH_EXPERIMENTAL build (IMH_EXPERIMENTAL=1 python -m imagharmony_amd.build; imagharmony_amd.lib.EXP_VARIANTS)"""
+    from imagharmony_amd import lib as L
+
+    def cfg_of(c):
+        if isinstance(c, dict):
+            return c.get("cfg")
+        if isinstance(c, tuple) and c and isinstance(c[0], tuple):
+            return c[0]
+        return c if isinstance(c, tuple) else None
+    return [c for c in cases if cfg_of(c) is None or len(cfg_of(c)) < 2 or L.variant_built(cfg_of(c))]
+
+
+def experimental():
+    from imagharmony_amd import lib as L
+    return L.experimental()
+
+
 def rel_rms(a, b):
     a = a.double().flatten()
     b = b.double().flatten()

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import ref_row_stats
+from conftest import built, ref_row_stats
 from test_gpu_ops import DEV, DTYPES, EPS, L, assert_close, ctx_for, geglu_ref, rnd, vt_unpermute  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -32,8 +32,8 @@ def _check_stats(st, slots, y, what):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg,width", [((2464, 160, 1), 80), ((1464, 160, 1), 80), ((24128, 160, 1), 80), ((22128, 160, 1), 80), ((24128, 128, 1), 64),
-                                       ((23256, 160, 1), 80), ((64, 64, 1), 32), ((128, 64, 1), 32), ((64, 128, 1), 64), ((128, 128, 1), 64)])
+@pytest.mark.parametrize("cfg,width", built([((2464, 160, 1), 80), ((1464, 160, 1), 80), ((24128, 160, 1), 80), ((22128, 160, 1), 80), ((24128, 128, 1), 64),
+                                       ((23256, 160, 1), 80), ((64, 64, 1), 32), ((128, 64, 1), 32), ((64, 128, 1), 64), ((128, 128, 1), 64)]))
 def test_statistics_epilogue(L, dtype, cfg, width):
     """ln_stats_out of every variant that has the epilogue, in the two forms the forward uses (proj_in: bias only; to_out /
     ff.out: bias + residual), ragged M included: slot sums / M2 of the values AS STORED (rounded to the output dtype)"""
@@ -63,11 +63,11 @@ def test_statistics_fallback_kernel_and_rejections(L, dtype):
     ctx = ctx_for(dtype)
     M, N, K = 300, 640, 256
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
-    for cfg in [(256, 128, 1), (3064, 64, 1), (64, 64, 2)]:
+    for cfg in [(5258, 320, 1), (3064, 64, 1), (64, 64, 2)]:
         y, (st, slots) = ctx.gemm(x, w, cfg=cfg, stats_out=True)
         assert slots == 1
         _check_stats(st, 1, y, f"row-statistics kernel behind {cfg}")
-    a = ctx.gemm(x, w, cfg=(256, 128, 1), _args_only=True)[0]
+    a = ctx.gemm(x, w, cfg=(5258, 320, 1), _args_only=True)[0]
     a.ln_stats_out, a.ln_slots_out = st.data_ptr(), 1
     assert ctx.lib.imh_gemm(a, ctx.stream()) == -1 and b"ln_stats_out" in ctx.lib.imh_last_error()
 
@@ -83,7 +83,7 @@ def _stats_for(ctx, x, how):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(23256, 160, 1), (2464, 160, 1), (1464, 160, 1), (24128, 160, 1), (22128, 160, 1), (24128, 128, 1), (128, 128, 1), (64, 64, 1)])
+@pytest.mark.parametrize("cfg", built([(23256, 160, 1), (2464, 160, 1), (1464, 160, 1), (24128, 160, 1), (22128, 160, 1), (24128, 128, 1), (128, 128, 1), (64, 64, 1)]))
 @pytest.mark.parametrize("how", [80, 32, "kernel"])
 def test_folded_layernorm_with_precomputed_statistics(L, dtype, cfg, how):
     """LN(x) W^T (+ GEGLU) with the statistics taken from the hand-over buffer, row form, every consuming variant; x with a
@@ -167,6 +167,8 @@ def test_large_common_offset_rows(L, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wave_specialised_projection_pair(L, dtype):
+    if not L.experimental():
+        pytest.skip("gemm_dual variant 24128 is compiled with -DIMH_EXPERIMENTAL only (the forward runs the one-launch [Q|K|V])")
     """variant 24128 of imh_gemm_dual: [Q|K] (row form, 128 x 160 tiles) + V^T (column form + V^T key permutation, 128 x 128
     tiles) in one wave-specialised launch with handed-over statistics -- the self-attention projections of the forward"""
     from imagharmony_amd.attention_processor import fold_ln

@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import built, experimental
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
@@ -66,7 +68,7 @@ BIG_VARIANTS = [(256, 128, 1), (256, 256, 1), (3128, 128, 1), (3064, 64, 1), (41
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", BIG_VARIANTS)
+@pytest.mark.parametrize("cfg", built(BIG_VARIANTS))
 def test_gemm_big_tile_variants(L, dtype, cfg):
     """every ring / KG2 / ping-pong variant on tile-aligned, ragged and single-K-tile shapes, with bias + residual, bitwise
     repeatable (the counted-vmcnt pipelines are race-screened by repetition)"""
@@ -89,7 +91,7 @@ def test_gemm_big_tile_variants(L, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(23256, 160, 1), (24128, 160, 1), (24128, 128, 1), (2464, 160, 1), (1464, 160, 1), (22128, 160, 1)])
+@pytest.mark.parametrize("cfg", built([(23256, 160, 1), (24128, 160, 1), (24128, 128, 1), (2464, 160, 1), (1464, 160, 1), (22128, 160, 1)]))
 def test_gemm_wave_specialised_folded_layernorm_geglu(L, dtype, cfg):
     """the wave-specialised kernels with the folded LayerNorm (row statistics from the row-statistics kernel, supplied by
     Ctx.gemm) and the GEGLU epilogue -- the ff.net.0 launch -- against F.layer_norm + matmul + gelu in fp32; the ping-pong
@@ -110,7 +112,7 @@ def test_gemm_wave_specialised_folded_layernorm_geglu(L, dtype, cfg):
         g = ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg)
         assert_close(g, geglu_ref(full), dtype, f"folded LN + GEGLU {cfg} {(M, N, K)}", k=8.0)
         assert torch.equal(g, ctx.gemm(x, wg, flags=L.GF_LN_ROW | L.GF_GEGLU, ln=(s, c, 1e-5), cfg=cfg))
-    for pp in [(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]:
+    for pp in built([(8256, 256, 1), (9128, 320, 1), (9256, 320, 1)]):
         with pytest.raises(L.ImhError, match="folded LayerNorm"):
             ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=pp)
 
@@ -187,7 +189,7 @@ def test_gemm_vt_perm(L, dtype, cfg):
 
 # ------------------------------------------------------------------------------------ conv
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [dict(B=2, H=16, W=16, Cin=64, Cout=128), dict(B=1, H=12, W=20, Cin=128, Cout=64),
+@pytest.mark.parametrize("case", built([dict(B=2, H=16, W=16, Cin=64, Cout=128), dict(B=1, H=12, W=20, Cin=128, Cout=64),
                                   dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2), dict(B=2, H=8, W=8, Cin=64, Cout=64, up=1),
                                   dict(B=2, H=8, W=8, Cin=192, Cout=4), dict(B=1, H=32, W=32, Cin=320, Cout=320, cfg=(128, 128, 2)),
                                   dict(B=1, H=32, W=32, Cin=128, Cout=640, cfg=(5258, 320, 1)), dict(B=2, H=16, W=24, Cin=64, Cout=320, up=1, cfg=(6128, 320, 1)),
@@ -207,7 +209,7 @@ def test_gemm_vt_perm(L, dtype, cfg):
                                   dict(B=2, H=8, W=8, Cin=64, Cout=160, up=1, cfg=(7128, 80, 1)),
                                   dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(1464, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(2464, 160, 1)),
                                   dict(B=1, H=24, W=24, Cin=64, Cout=160, stride=2, cfg=(2464, 160, 2)),
-                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(24128, 160, 1)), dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(22128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(24128, 128, 1))])
+                                  dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(24128, 160, 1)), dict(B=2, H=16, W=16, Cin=128, Cout=320, cfg=(22128, 160, 1)), dict(B=1, H=12, W=20, Cin=64, Cout=200, up=1, cfg=(24128, 128, 1))]))
 def test_conv3x3(L, dtype, case):
     ctx = ctx_for(dtype)
     B, H, W, Cin, Cout = case["B"], case["H"], case["W"], case["Cin"], case["Cout"]
@@ -245,7 +247,7 @@ def sdpa_ref(q, k, v, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3] + ([5, 6] if experimental() else []))      # 5 / 6: the key-split kernel (-DIMH_EXPERIMENTAL)
 @pytest.mark.parametrize("B,H,Lq", [(2, 2, 256), (1, 5, 1024), (2, 1, 64), (1, 2, 192), (1, 3, 128), (2, 1, 320), (1, 2, 384), (1, 1, 448),
                                     (1, 1, 512), (1, 2, 4096), (2, 3, 640), (1, 2, 768)])
 def test_attention_self(L, dtype, mode, B, H, Lq):
@@ -301,7 +303,7 @@ def test_attention_cross_ip(L, dtype, B, H, Lq, nt, nip):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1] + ([2, 3, 4] if experimental() else []))      # 2 .. 4: the two-head kernel (-DIMH_EXPERIMENTAL)
 @pytest.mark.parametrize("B,H,Lq,nt,nip,ln", [(2, 2, 256, 77, 4, 1), (1, 20, 128, 77, 16, 2), (2, 5, 100, 77, 32, 0), (2, 4, 100, 77, 32, 2),
                                                (1, 10, 192, 130, 0, 1), (2, 20, 1024, 77, 4, 2), (2, 20, 1024, 77, 0, 3), (2, 10, 4096, 77, 0, 0)])
 def test_fused_cross_attention(L, dtype, mode, B, H, Lq, nt, nip, ln):
@@ -360,7 +362,7 @@ def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_st
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1] + ([3] if experimental() else []))
 @pytest.mark.parametrize("how", ["epilogue", "kernel", "ctx"])
 def test_fused_cross_attention_large_mean_rows(L, dtype, mode, how):
     """norm2 folded into the fused cross-attention's to_q on rows with |mean| >> sigma (x = 50 + N(0, 0.1) as
@@ -417,7 +419,7 @@ def test_fused_cross_attention_large_mean_rows(L, dtype, mode, how):
     assert zr < 0.2, f"zero-variance row rel-rms {zr:.3e}"
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 5])
+@pytest.mark.parametrize("mode", [1, 2, 3] + ([5] if experimental() else []))
 def test_attention_spiked_scores(L, mode):
     """forces the online-softmax rescale path: one key dominates late in the sequence (every key loop)"""
     assert L.load().imh_debug_set(4, mode) == 0
@@ -428,7 +430,7 @@ def test_attention_spiked_scores(L, mode):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mode", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("mode", [1, 2, 3] + ([5, 6] if experimental() else []))
 def test_attention_creeping_maximum(L, dtype, mode):
     """the deferred running maximum (mode 3 = the default of the pipelined loop): every 64-key tile raises the row maxima by
     ~3 in the exponent domain, below the 2^8 deferral threshold per tile but 45 in total -- the rescale must fire every third

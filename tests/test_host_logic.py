@@ -257,6 +257,9 @@ def test_every_tuning_entry_names_a_variant_the_dispatcher_knows():
             assert pp[bm] == bn and conv == 0 and splits == 1, key
         else:
             assert (bm, bn) in known, f"{key}: variant {bm} x {bn} is not in the dispatch tables"
+        # ... and it must be one the DEFAULT library compiles: the measured-but-not-selected variants exist only with -DIMH_EXPERIMENTAL
+        from imagharmony_amd import lib as L
+        assert (bm, bn) not in L.EXP_VARIANTS, f"{key}: variant {bm} x {bn} is an experimental-only variant"
 
 
 def test_folded_layernorm_launches_only_get_variants_that_implement_it():
