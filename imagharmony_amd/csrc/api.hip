@@ -42,6 +42,10 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.ln_stats = a->ln_stats; p.ln_stats_out = a->ln_stats_out; p.ln_slots = a->ln_slots; p.ln_slots_out = a->ln_slots_out;
     p.gn_out = a->gn_out; p.gn_nblk = a->gn_nblk; p.gn_hw = a->gn_hw;
     p.gn_tab = a->gn_tab; p.gn_silu = a->gn_silu; p.X2 = a->X2; p.Cin1 = a->X2 ? a->Cin1 : a->Cin;
+    p.gn_src.partial = a->gn_part; p.gn_src.partial2 = a->gn_part2; p.gn_src.gamma = a->gn_gamma; p.gn_src.beta = a->gn_beta;
+    p.gn_src.eps = a->gn_eps; p.gn_src.groups = a->gn_groups; p.gn_src.C = a->Cin; p.gn_src.C1 = a->gn_part2 ? a->gn_pC1 : a->Cin;
+    p.gn_src.HW = a->H * a->Wd; p.gn_src.nblk = a->gn_pnblk; p.gn_src.sub = a->gn_psub; p.gn_src.npart = a->gn_pnpart;
+    p.gn_src.nblk2 = a->gn_pnblk2; p.gn_src.sub2 = a->gn_psub2; p.gn_src.npart2 = a->gn_pnpart2; p.gn_src.dtype_f16 = a->dtype == IMH_DT_F16;
     p.Yt = a->Yt; p.yt_col0 = a->yt_col0; p.ldyt = a->ldyt;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr; p.ldra = a->ldra > 0 ? a->ldra : a->N;

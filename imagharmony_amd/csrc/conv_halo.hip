@@ -235,8 +235,16 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
     const int nW = (WQ - 1) + ((WQ - 1) * NWS + widx < WPIECES ? 1 : 0);      // (per step)
     const int nH = (HWV && !SVC) ? 0 : (HQ - 1) + ((HQ - 1) * NSTG + (sw < 0 ? 0 : sw) < HPIECES ? 1 : 0);
     auto step_ct = [&](int st) { return st / SPC; };
-    const bool gn = p.gn_tab != nullptr;
-    if (gn) {                                           // this sample's (scale, shift) table -> LDS, before any LDS-DMA is in flight
+    const bool gn = p.gn_tab != nullptr || p.gn_src.partial != nullptr;
+    // this sample's table built right here from the producers' partials (imh_gntable.h): no table launch.  With extra waves the EIGHT MFMA
+    // waves build it (32 quarter waves = the 32 groups in one round) while the extra waves already have the first halo (and, as service
+    // waves, the weight ring's prologue) in flight -- the cold read of the partials hides under the first LDS-DMA round trip; one raw
+    // s_barrier hands the table over (a __syncthreads() would drain the extra waves' LDS-DMA queue)
+    const bool own_tab = p.gn_src.partial != nullptr;
+    if (own_tab && HWV == 0) {
+        gn_table_of_sample(p.gn_src, b, (float*)gtab, tid / GN_GL, NT / GN_GL, lane);
+        __syncthreads();
+    } else if (gn && !own_tab) {                                    // ... or copied from a table launch's output; -> LDS before any LDS-DMA is in flight
         const f32x4* src = (const f32x4*)(p.gn_tab + (size_t)b * p.Cin * 2);
         f32x4* dst = (f32x4*)gtab;
         for (int i = tid; i < p.Cin / 2; i += NT) dst[i] = src[i];
@@ -252,6 +260,10 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                     if (j < nsteps) stage_w(j % S, step_ct(j), j - SPC * step_ct(j));
             }
             stage_halo(0, 0);
+            if (own_tab) {                                      // the MFMA waves' table (below) is complete
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (gn) norm_halo(0, 0, 0, HQ);
 #if CH_TIMING
@@ -304,6 +316,14 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
             tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid - 512, 64 * HWV);
 #endif
             return;
+        }
+    }
+    if constexpr (HWV > 0) {
+        if (own_tab) {
+            gn_table_of_sample(p.gn_src, b, (float*)gtab, tid / GN_GL, 512 / GN_GL, lane);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the table rows are in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
     if constexpr (HWV == 0) stage_halo(0, 0);           // oldest: whoever waits for weight step 0 has the first halo too
@@ -461,12 +481,13 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     const int B = p.M / (p.Ho * p.Wo);
     const int tiles_x = (p.Wo + CH_PW - 1) / CH_PW, tiles_y = (p.Ho + ph - 1) / ph, tiles_n = (p.N + bn - 1) / bn;
     dim3 grid(B * tiles_y * tiles_x * tiles_n);
-    if (p.gn_tab && p.up) { set_error("conv_halo: the fused GroupNorm front end and the fused upsampling are separate forms"); return IMH_ERR_ARG; }
+    const bool gnf = p.gn_tab || p.gn_src.partial;
+    if (gnf && p.up) { set_error("conv_halo: the fused GroupNorm front end and the fused upsampling are separate forms"); return IMH_ERR_ARG; }
     if (p.Cin1 % GEMM_BK != 0 || p.Cin1 <= 0 || p.Cin1 > p.Cin || (p.X2 == nullptr) != (p.Cin1 == p.Cin)) {
         set_error("conv_halo: Cin1=%d must be a positive multiple of 64, = Cin=%d exactly when there is no second source", p.Cin1, p.Cin);
         return IMH_ERR_ARG;
     }
-    int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * (ks ? 3 : 1) * bn * GEMM_ROW_BYTES + (p.gn_tab ? p.Cin * 8 : 0);
+    int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * (ks ? 3 : 1) * bn * GEMM_ROW_BYTES + (gnf ? p.Cin * 8 : 0);
     if (ks && lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;       // the pairs' accumulator exchange (40 KB) reuses the staging area
     if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
     // the fused GroupNorm front end runs on the form with four halo waves (the input side off the MFMA waves); g_halo_mode

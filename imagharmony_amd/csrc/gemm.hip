@@ -496,8 +496,14 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
     {
         const bool halo = bm >= 7000 && bm < 8000;
         const bool ws = bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128;
-        if (p.gn_tab && !(conv && halo)) {
-            set_error("gemm: the fused GroupNorm front end (gn_tab) is a form of the LDS-halo conv3x3 (variant %d)", bm);
+        if ((p.gn_tab || p.gn_src.partial) && !(conv && halo)) {
+            set_error("gemm: the fused GroupNorm front end (gn_tab / gn_part) is a form of the LDS-halo conv3x3 (variant %d)", bm);
+            return IMH_ERR_ARG;
+        }
+        if (p.gn_src.partial && (p.gn_tab || !gn_src_ok(p.gn_src))) {
+            set_error("gemm: gn_part (in-kernel GroupNorm table) is exclusive with gn_tab and needs partials whose sub-runs tile the groups "
+                      "(Cin=%d groups=%d C1=%d sub=%d/%d nblk=%d/%d), eps > 0", p.Cin, p.gn_src.groups, p.gn_src.C1, p.gn_src.sub, p.gn_src.sub2,
+                      p.gn_src.nblk, p.gn_src.nblk2);
             return IMH_ERR_ARG;
         }
         if (p.X2 && conv && !halo) { set_error("gemm: a two-source conv input (X2) needs the LDS-halo conv3x3 (variant %d)", bm); return IMH_ERR_ARG; }

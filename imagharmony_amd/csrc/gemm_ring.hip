@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // Those problems tile 256 ways only as 64 x 160, and at that size the vector-memory front end is the longest
 // pipe of the CU: every 16-B piece of both operands goes through the address unit at 64 B / clk / CU
 // (tools/micro/glds_rate.hip), 448 cycles per K tile against 320 cycles of MFMA time, and a wave that is queued
-// behind that unit with an LDS-DMA instruction cannot issue its MFMAs (tools/hot_probe.py: cache-hot operands
+// behind that unit with an LDS-DMA instruction cannot issue its MFMAs (round-2 probe with cache-hot operands
 // change nothing).  So the roles are split: NP producer waves do nothing but issue the LDS-DMA ring (own vmcnt
 // counters, S - 1 tiles ahead), CM x CN consumer waves only read fragments and issue MFMAs, with the fragments of
 // k step kk + 1 read into a second register set while the MFMAs of k step kk run, so that a consumer never waits

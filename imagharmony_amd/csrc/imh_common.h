@@ -80,7 +80,7 @@ static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256]; 
 // Tail prefetch: before a workgroup exits it touches its slice (one dword per 128-B line) of the NEXT kernel's
 // weight matrix, pulling it from HBM into L2 / Infinity Cache while the rest of this kernel is still running.
 // Every layer's weights are read exactly once per UNet forward (5 GB per forward), so without this each GEMM
-// starts on cold HBM lines (+2..13 us per launch measured, tools/cold_weights.py).  Purely a cache hint.
+// starts on cold HBM lines (+2..13 us per launch measured in round 2).  Purely a cache hint.
 __device__ __forceinline__ void tail_prefetch(const void* ptr, unsigned bytes, unsigned bid, unsigned nblocks,
                                               unsigned tid, unsigned nthreads) {
     if (!ptr) return;

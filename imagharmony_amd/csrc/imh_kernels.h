@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "imh_gntable.h"
 
 namespace imh {
 
@@ -31,6 +32,7 @@ struct GemmParams {
     // GroupNorm (+ SiLU) of the INPUT applied inside the conv's halo staging (conv_halo.hip): table[b][Cin][2] = (scale, shift)
     const float* gn_tab;
     int gn_silu;
+    GnTabSrc gn_src;       // ... or the input's GroupNorm partials: the kernel builds its sample's table in LDS (gn_src.partial != null)
     // channel concat as the conv input: channels [0, Cin1) come from X (pixel stride Cin1), [Cin1, Cin) from X2 (pixel stride Cin - Cin1)
     const void* X2;
     int Cin1;

@@ -7,6 +7,7 @@
 // HarmonyAttention.ln (train.py:238).
 #include "imh_common.h"
 #include "imh_kernels.h"
+#include "imh_gntable.h"
 #include <algorithm>
 
 namespace imh {
@@ -108,82 +109,35 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const NormParams p
     }
 }
 
-// step 2: one workgroup per (sample, group): its 256 threads stride over the group's partials -- (pixel block, sub-run) pairs of
-// one or two sources -- with one load each per round, adding up in double S = sum_i sum_i, Q = sum_i (M2_i + sum_i^2 / n_i),
-// N = sum_i n_i; a fixed-order reduction (lanes by butterfly, waves through LDS: deterministic) gives mean = S / N,
-// var = (Q - S^2 / N) / N -- the between-partial term in double, the within-partial terms already centred -- and the group's cpg
-// threads write (scale, shift).  Source 1 covers channels [0, C1), source 2 (optional) [C1, C).  npart > 0: elements per partial (a
-// producer epilogue: block rows x sub); npart == 0: the ragged blocks of gn_stats_kernel ((pixels of block k) * sub, ppb = ceil(HW /
-// nblk)).  (The first version ran one workgroup per SAMPLE with a serial walk per group: 10-16 us per launch, 46 launches per
-// forward -- profiles/r04_forward_ab_gn.json.)
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// step 2 (imh_gntable.h): one QUARTER wave per (sample, group) -- its 16 lanes stride over the group's partials of one or two sources in
+// double, a fixed-order butterfly, then the group's (scale, shift) rows.  The same routine runs in the prologue of the consumers that
+// build their sample's table themselves (conv_halo.hip with imh_gemm_args.gn_part, gn_apply_kernel below with IMH_GN_TABLE_APPLY): the
+// stand-alone launch is left for consumers that share one table (the implicit-GEMM convs, tests).
+static inline GnTabSrc gn_src_of(const NormParams& p) {
+    GnTabSrc g;
+    g.partial = p.partial; g.partial2 = p.partial2; g.gamma = p.gamma; g.beta = p.beta; g.eps = p.eps;
+    g.groups = p.groups; g.C = p.C; g.C1 = p.partial2 ? p.C1 : p.C; g.HW = p.HW;
+    g.nblk = p.nblk; g.sub = p.sub; g.npart = p.npart; g.nblk2 = p.nblk2; g.sub2 = p.sub2; g.npart2 = p.npart2;
+    g.dtype_f16 = p.dtype_f16;
+    return g;
 }
-__global__ __launch_bounds__(256) void gn_table_kernel(const NormParams p) {
-    __shared__ double red[3][4];
-    __shared__ float ms[2];
-    const int gg = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-    const int C = p.C, cpg = C / p.groups;
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    double S = 0.0, Q = 0.0, N = 0.0;
-    const int c0 = gg * cpg, c1 = c0 + cpg;
-#pragma unroll 1
-    for (int src = 0; src < 2; ++src) {
-        const float* pp = src == 0 ? p.partial : p.partial2;
-        if (!pp) continue;
-        const int cb = src == 0 ? 0 : p.C1, ce = src == 0 ? p.C1 : C;          // channel range of this source
-        const int lo = max(c0, cb), hi = min(c1, ce);
-        if (lo >= hi) continue;
-        const int sub = src == 0 ? p.sub : p.sub2, nblk = src == 0 ? p.nblk : p.nblk2, npart = src == 0 ? p.npart : p.npart2;
-        const int nsub = (ce - cb) / sub;
-        const int j0 = (lo - cb) / sub, nj = (hi - cb) / sub - j0;
-        const int ppb = (p.HW + nblk - 1) / nblk;
-        const f2* base = (const f2*)pp + (size_t)b * nblk * nsub + j0;
-        const int total = nblk * nj;
-        const double inv_const = npart > 0 ? 1.0 / (double)npart : 0.0;
-        for (int e = t; e < total; e += 256) {
-            const int k = e / nj, j = e - k * nj;
-            const f2 v = base[(size_t)k * nsub + j];
-            double n, inv;
-            if (npart > 0) { n = (double)npart; inv = inv_const; }
-            else { n = (double)(min(p.HW, (k + 1) * ppb) - k * ppb) * sub; inv = n > 0.0 ? 1.0 / n : 0.0; }
-            if (n > 0.0) {
-                S += (double)v[0];
-                Q += (double)v[1] + (double)v[0] * (double)v[0] * inv;
-                N += n;
-            }
-        }
-    }
-    S = wave_sum_d(S); Q = wave_sum_d(Q); N = wave_sum_d(N);
-    if ((t & 63) == 0) { red[0][t >> 6] = S; red[1][t >> 6] = Q; red[2][t >> 6] = N; }
-    __syncthreads();
-    if (t == 0) {
-        const double S4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const double Q4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        const double N4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-        const double mean = S4 / N4;
-        double var = (Q4 - S4 * S4 / N4) / N4;
-        if (var < 0.0) var = 0.0;
-        ms[0] = (float)mean;
-        ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
-    __syncthreads();
-    float* tab = p.table + (size_t)b * C * 2;
-    for (int c = c0 + t; c < c1; c += 256) {
-        const float gm = p.gamma ? (p.dtype_f16 ? to_f32(((const f16_t*)p.gamma)[c]) : to_f32(((const bf16_t*)p.gamma)[c])) : 1.f;
-        const float bt = p.beta ? (p.dtype_f16 ? to_f32(((const f16_t*)p.beta)[c]) : to_f32(((const bf16_t*)p.beta)[c])) : 0.f;
-        const float sc = gm * ms[1];
-        f2 o = {sc, bt - ms[0] * sc};
-        *(f2*)(tab + (size_t)c * 2) = o;
-    }
+__global__ __launch_bounds__(256) void gn_table_kernel(const GnTabSrc g, float* table) {
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int gg = blockIdx.x * (256 / GN_GL) + t / GN_GL;        // sixteen groups per workgroup
+    if (gg >= g.groups) return;                                   // (whole quarter waves leave together)
+    GnRows r;
+    gn_rows_fetch(g, gg, t & (GN_GL - 1), r);
+    float mean, rstd;
+    gn_group_stats(g, b, gg, t & (GN_GL - 1), mean, rstd);
+    gn_group_rows(g, gg, t & (GN_GL - 1), mean, rstd, r, table + (size_t)b * g.C * 2);
 }
 
 // step 3, stand-alone: y = silu?(x * scale[c] + shift[c]) with the per-sample table of step 2
-template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk) {
+// OWN: the table of the workgroup's sample is built here, in LDS, from the producers' partials (IMH_GN_TABLE_APPLY) -- no table launch
+template <typename T, bool OWN>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p, int nblk, const GnTabSrc g) {
     typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) float gn_lds_tab[];      // OWN: [C][2]
     tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, GN_THREADS);
     const int C = p.C, CL = C >> 3;
     const int P = max(1, GN_THREADS / CL);
@@ -191,11 +145,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
     const int ppb = (p.HW + nblk - 1) / nblk;
     const int start = blk * ppb, end = min(p.HW, start + ppb);
     const int t = threadIdx.x;
+    if constexpr (OWN) {
+        gn_table_of_sample(g, b, gn_lds_tab, t / GN_GL, GN_THREADS / GN_GL, t & 63);
+        __syncthreads();
+    }
     if (t < CL * P) {
         const int cl = t % CL, pl = t / CL;
         float sc[8], sh[8];
         {
-            const f32x4* tb = (const f32x4*)(p.table + ((size_t)b * C + cl * 8) * 2);
+            const f32x4* tb = OWN ? (const f32x4*)(gn_lds_tab + (size_t)cl * 8 * 2) : (const f32x4*)(p.table + ((size_t)b * C + cl * 8) * 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
         }
@@ -222,7 +180,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const NormParams p
 }
 
 // mode: IMH_GN_ALL statistics + table + apply (workspace in p.partial: partials, then the table); IMH_GN_STATS statistics only
-// (-> p.partial); IMH_GN_TABLE table from the partials of one or two producers (-> p.table); IMH_GN_APPLY apply p.table
+// (-> p.partial); IMH_GN_TABLE table from the partials of one or two producers (-> p.table); IMH_GN_APPLY apply p.table;
+// IMH_GN_TABLE_APPLY partials -> y in ONE launch (every workgroup builds its sample's table in LDS)
 int groupnorm_launch(const NormParams& p0, int dtype, hipStream_t stream) {
     NormParams p = p0;
     if (p.C % 8 || p.groups <= 0 || p.groups > 64 || p.C % p.groups || (p.C >> 3) > GN_THREADS || p.B <= 0 || p.HW <= 0) {
@@ -233,8 +192,22 @@ int groupnorm_launch(const NormParams& p0, int dtype, hipStream_t stream) {
     p.dtype_f16 = dtype == IMH_DT_F16;
     const int nblk = gn_nblk(p.HW, p.C);
     const int mode = p.mode;
-    if (mode < 0 || mode > 3) { set_error("groupnorm: unknown mode %d", mode); return IMH_ERR_ARG; }
+    if (mode < 0 || mode > 4) { set_error("groupnorm: unknown mode %d", mode); return IMH_ERR_ARG; }
     const int cpg = p.C / p.groups;
+    if (mode == 4) {          // IMH_GN_TABLE_APPLY: partials -> (table in LDS, per workgroup) -> y
+        if (!p.partial2) p.C1 = p.C;
+        const GnTabSrc g = gn_src_of(p);
+        if (!p.x || !p.y || !gn_src_ok(g)) {
+            set_error("groupnorm table+apply: needs x, y and partials whose sub-runs tile the groups (C=%d groups=%d C1=%d sub=%d/%d nblk=%d/%d), eps > 0",
+                      p.C, p.groups, p.C1, p.sub, p.sub2, p.nblk, p.nblk2);
+            return IMH_ERR_ARG;
+        }
+        const size_t lds = (size_t)p.C * 2 * sizeof(float);
+        dim3 grid(nblk, p.B);
+        if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), grid, dim3(GN_THREADS), lds, stream, p, nblk, g);
+        else hipLaunchKernelGGL((gn_apply_kernel<f16_t, true>), grid, dim3(GN_THREADS), lds, stream, p, nblk, g);
+        return check_launch("groupnorm table+apply");
+    }
     if (mode == 0 || mode == 1) {
         if (!p.x || !p.partial) { set_error("groupnorm: statistics need x and a partial / workspace buffer"); return p.x ? IMH_ERR_WORKSPACE : IMH_ERR_ARG; }
         const int sub = mode == 0 ? gn_sub(p.C, p.groups) : p.sub;
@@ -253,19 +226,18 @@ int groupnorm_launch(const NormParams& p0, int dtype, hipStream_t stream) {
     if (mode == 0 || mode == 2) {
         if (!p.partial || !p.table) { set_error("groupnorm: the table step needs partials and a table buffer"); return IMH_ERR_ARG; }
         if (!p.partial2) p.C1 = p.C;
-        const bool two = p.partial2 != nullptr;
-        if (p.sub <= 0 || p.nblk <= 0 || p.C1 <= 0 || p.C1 > p.C || p.C1 % p.sub || cpg % p.sub || (two && (p.sub2 <= 0 || p.nblk2 <= 0 || (p.C - p.C1) % p.sub2 || cpg % p.sub2 || p.C1 % p.sub2))
-            || !(p.eps > 0.f)) {
+        const GnTabSrc g = gn_src_of(p);
+        if (!gn_src_ok(g)) {
             set_error("groupnorm table: sub-runs must tile the groups (C=%d groups=%d C1=%d sub=%d/%d nblk=%d/%d) and eps > 0", p.C, p.groups, p.C1, p.sub, p.sub2, p.nblk, p.nblk2);
             return IMH_ERR_ARG;
         }
-        hipLaunchKernelGGL(gn_table_kernel, dim3(p.groups, p.B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gn_table_kernel, dim3((p.groups * GN_GL + 255) / 256, p.B), dim3(256), 0, stream, g, p.table);
         if (mode == 2) return check_launch("gn_table_kernel");
     }
     if (!p.x || !p.y || !p.table) { set_error("groupnorm: apply needs x, y and a table"); return IMH_ERR_ARG; }
     dim3 grid(nblk, p.B);
-    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
-    else hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(GN_THREADS), 0, stream, p, nblk);
+    if (dtype == IMH_DT_BF16) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), grid, dim3(GN_THREADS), 0, stream, p, nblk, GnTabSrc{});
+    else hipLaunchKernelGGL((gn_apply_kernel<f16_t, false>), grid, dim3(GN_THREADS), 0, stream, p, nblk, GnTabSrc{});
     return check_launch("groupnorm");
 }
 

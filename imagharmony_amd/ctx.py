@@ -48,6 +48,27 @@ class GnStats:
         self.t, self.nblk, self.sub, self.npart, self.C = t, int(nblk), int(sub), int(npart), int(C_)
 
 
+class GnSpec:
+    """A GroupNorm as its consumer's prologue sees it (round 5): the statistics of the input (one GnStats, or two for a channel concat),
+    gamma / beta, groups, eps -- the consuming launch builds the (scale, shift) table of its sample itself (imh_gemm_args.gn_part /
+    IMH_GN_TABLE_APPLY) instead of reading one written by a table launch."""
+    def __init__(self, stats, gamma, beta, groups, eps):
+        self.srcs = list(stats) if isinstance(stats, (list, tuple)) else [stats]
+        self.gamma, self.beta, self.groups, self.eps = gamma, beta, int(groups), float(eps)
+        self.C = sum(g.C for g in self.srcs)
+
+    def check(self, B, Cc, descr):
+        if not 1 <= len(self.srcs) <= 2 or self.C != Cc:
+            raise L.ImhError(f"{descr}: statistics of {self.C} channels from {len(self.srcs)} source(s) do not fit C={Cc}")
+        cpg = Cc // self.groups
+        for g in self.srcs:
+            if tuple(g.t.shape) != (B, g.nblk, g.C // g.sub, 2) or g.t.dtype != torch.float32 or cpg % g.sub or self.srcs[0].C % g.sub:
+                raise L.ImhError(f"{descr}: statistics {tuple(g.t.shape)} (sub {g.sub}) do not fit C={Cc}, groups={self.groups}")
+
+    def tensors(self):
+        return tuple(g.t for g in self.srcs) + (self.gamma, self.beta)
+
+
 class Ctx:
     def __init__(self, device, dtype=torch.bfloat16, record=False, dry=False):
         """dry=True (record only): tensors may live on the CPU; the plan can be inspected (op list,
@@ -399,9 +420,10 @@ class Ctx:
                 descr="conv3x3", gn_groups=0, gn=None, x2=None):
         """x: NHWC [B, H, W, Cin]; w: packed [Cout, 9*Cin]; returns NHWC [B, Ho, Wo, Cout]; with gn_groups > 0 (the output is
         a GroupNorm input) -> (y, GnStats or None) as gemm(gn_out=...).
-        gn = (table [B, Cin, 2] fp32 from gn_table(), silu): the input's GroupNorm (+ SiLU) is applied inside the kernel's halo
-        staging (diffusers ResnetBlock2D: norm -> nonlinearity -> conv in one launch); x2: the input is the channel concat
-        [x | x2].  Both need the LDS-halo variant (conv_fuses_gn)."""
+        gn = (table [B, Cin, 2] fp32 from gn_table(), silu) or (GnSpec, silu): the input's GroupNorm (+ SiLU) is applied inside the
+        kernel's halo staging (diffusers ResnetBlock2D: norm -> nonlinearity -> conv in one launch) -- with a GnSpec the kernel also builds
+        the table itself from the producers' partials (no table launch); x2: the input is the channel concat [x | x2].  Both need the
+        LDS-halo variant (conv_fuses_gn)."""
         self._chk(x, descr + ".x"); self._chk(w, descr + ".w")
         B, H, W, C1 = x.shape
         Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
@@ -436,18 +458,30 @@ class Ctx:
         a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.stride, a.up = H, W, Cin, Ho, Wo, stride, up
         if x2 is not None:
             a.X2, a.Cin1 = x2.data_ptr(), C1
-        if gn is not None:
+        gn_keep = ()
+        if gn is not None and isinstance(gn[0], GnSpec):
+            sp_, silu = gn
+            sp_.check(B, Cin, descr)
+            s0 = sp_.srcs[0]
+            a.gn_part, a.gn_pnblk, a.gn_psub, a.gn_pnpart, a.gn_pC1 = s0.t.data_ptr(), s0.nblk, s0.sub, s0.npart, s0.C
+            if len(sp_.srcs) == 2:
+                s1 = sp_.srcs[1]
+                a.gn_part2, a.gn_pnblk2, a.gn_psub2, a.gn_pnpart2 = s1.t.data_ptr(), s1.nblk, s1.sub, s1.npart
+            a.gn_gamma, a.gn_beta, a.gn_groups, a.gn_eps, a.gn_silu = self._p(sp_.gamma), self._p(sp_.beta), sp_.groups, sp_.eps, int(bool(silu))
+            gn_keep = sp_.tensors()
+        elif gn is not None:
             tab, silu = gn
             if tuple(tab.shape) != (B, Cin, 2) or tab.dtype != torch.float32 or not tab.is_contiguous():
                 raise L.ImhError(f"{descr}: GroupNorm table {tuple(tab.shape)} does not fit [{B}, {Cin}, 2] fp32")
             a.gn_tab, a.gn_silu = tab.data_ptr(), int(bool(silu))
+            gn_keep = (tab,)
         if sp > 1:
             a.partial = self.workspace(self.lib.imh_gemm_workspace_bytes(M, N, sp)).data_ptr()
         gs = self._gn_epilogue(a, Ho * Wo) if gn_groups else None
         es = x.element_size()
         self._emit(L.OP_GEMM, a, descr=descr, flops=2.0 * M * N * K,
                    nbytes=es * (B * H * W * Cin + N * K + M * N),
-                   keep=(x, w, out, bias, rowadd, residual, x2) + ((gs.t,) if gs else ()) + ((gn[0],) if gn is not None else ()),
+                   keep=(x, w, out, bias, rowadd, residual, x2) + ((gs.t,) if gs else ()) + gn_keep,
                    shape=(M, N, K, 1, (B, H, W, Cin, stride, up)),
                    epi=dict(flags=0, bias=bias is not None, residual=residual is not None, rowadd=rowadd is not None,
                             rows_per_batch=Ho * Wo, cfg=(bm, bn, sp), gn_out=(gs.nblk, Ho * Wo) if gs else None,
@@ -578,6 +612,26 @@ class Ctx:
         self._emit(L.OP_GROUPNORM, a, descr=descr, flops=4.0 * x.numel(), nbytes=2.0 * es * x.numel(), keep=(x, out, tab))
         return out
 
+    def gn_table_apply(self, x, spec, silu, out=None, descr="gn_table_apply"):
+        """y = silu?(GroupNorm(x)) in ONE launch from the producers' partials (IMH_GN_TABLE_APPLY): every workgroup of the apply pass
+        builds its sample's table in LDS -- the form for consumers that cannot take the norm themselves (Transformer2DModel.norm in
+        front of proj_in, conv_norm_out)"""
+        self._chk(x, descr + ".x")
+        B, HW, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+        spec.check(B, Cc, descr)
+        if out is None:
+            out = self.new(*x.shape)
+        a = self._norm_args(B, HW, Cc, spec.groups, spec.eps, silu, L.GN_TABLE_APPLY)
+        a.x, a.y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), self._p(spec.gamma), self._p(spec.beta)
+        s0 = spec.srcs[0]
+        a.partial, a.nblk, a.sub, a.npart, a.C1 = s0.t.data_ptr(), s0.nblk, s0.sub, s0.npart, s0.C
+        if len(spec.srcs) == 2:
+            s1 = spec.srcs[1]
+            a.partial2, a.nblk2, a.sub2, a.npart2 = s1.t.data_ptr(), s1.nblk, s1.sub, s1.npart
+        es = x.element_size()
+        self._emit(L.OP_GROUPNORM, a, descr=descr, flops=4.0 * x.numel(), nbytes=2.0 * es * x.numel(), keep=(x, out) + spec.tensors())
+        return out
+
     def groupnorm(self, x, gamma, beta, groups, eps, silu, out=None, descr="groupnorm", stats=None):
         """x: [B, HW, C] (NHWC flattened).  stats = GnStats left by the producing launch's epilogue (gemm(gn_out=...) /
         conv3x3(gn_groups=...)) or by gn_stats(): table + apply, no statistics pass over x; None: statistics + table + apply."""
@@ -586,10 +640,7 @@ class Ctx:
         if stats is not None:
             if not isinstance(stats, GnStats) or stats.C != Cc or stats.t.shape[0] != B:
                 raise L.ImhError(f"{descr}: statistics do not fit x {tuple(x.shape)}")
-            tab = self.gn_table(stats, gamma, beta, groups, eps, HW, descr=descr + ".table")
-            y = self.gn_apply(x, tab, silu, out=out, descr=descr)
-            self.free(tab)
-            return y
+            return self.gn_table_apply(x, GnSpec(stats, gamma, beta, groups, eps), silu, out=out, descr=descr)
         if out is None:
             out = self.new(*x.shape)
         a = self._norm_args(B, HW, Cc, groups, eps, silu, L.GN_ALL)
@@ -666,7 +717,7 @@ class Ctx:
                 return False
             # of the GroupNorm launches only the apply pass touches its prefetch slot (gn_apply_kernel); a table / statistics launch
             # would swallow the pointer and the cold conv weights behind it would never be prefetched
-            if kind == L.OP_GROUPNORM and a.mode not in (L.GN_ALL, L.GN_APPLY):
+            if kind == L.OP_GROUPNORM and a.mode not in (L.GN_ALL, L.GN_APPLY, L.GN_TABLE_APPLY):
                 return False
             return True
 

@@ -10,11 +10,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
-GN_ALL, GN_STATS, GN_TABLE, GN_APPLY = 0, 1, 2, 3
+GN_ALL, GN_STATS, GN_TABLE, GN_APPLY, GN_TABLE_APPLY = 0, 1, 2, 3, 4
 (EW_TIMESTEP, EW_SILU, EW_CONCAT, EW_CONV_IN, EW_CFG_STEP, EW_CAST_F32, EW_ADD, EW_STEP_SET, EW_CFG_RESCALE, EW_SOFTMAX,
  EW_ROW_STATS, EW_STEP_ROW) = range(12)
 
@@ -40,7 +40,10 @@ class GemmArgs(C.Structure):
     _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("partial", _vp), ("bias", _vp), ("rowadd", _vp),
                 ("residual", _vp), ("ln_s", _vp), ("ln_c", _vp), ("ln_eps", _f32),
                 ("ln_stats", _vp), ("ln_stats_out", _vp), ("ln_slots", _i32), ("ln_slots_out", _i32),
-                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_hw", _i32), ("gn_tab", _vp), ("gn_silu", _i32), ("X2", _vp), ("Cin1", _i32), ("Yt", _vp), ("yt_col0", _i32), ("ldyt", _i32),
+                ("gn_out", _vp), ("gn_nblk", _i32), ("gn_hw", _i32), ("gn_tab", _vp), ("gn_silu", _i32),
+                ("gn_part", _vp), ("gn_part2", _vp), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_eps", _f32), ("gn_groups", _i32), ("gn_pC1", _i32),
+                ("gn_pnblk", _i32), ("gn_psub", _i32), ("gn_pnpart", _i32), ("gn_pnblk2", _i32), ("gn_psub2", _i32), ("gn_pnpart2", _i32),
+                ("X2", _vp), ("Cin1", _i32), ("Yt", _vp), ("yt_col0", _i32), ("ldyt", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32), ("ldra", _i32),
                 ("rows_per_batch", _i32), ("splits", _i32), ("flags", _i32),

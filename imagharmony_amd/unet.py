@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import lib as L
 from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0, _b, _vkey, _w
-from .ctx import Ctx
+from .ctx import Ctx, GnSpec
 
 
 # BasicTransformerBlock.norm1/2/3 folded into the consumer GEMMs (exact algebra, tested): the consumer takes the
@@ -54,6 +54,11 @@ GN_STATS_HANDOVER = os.environ.get("IMH_GN_STATS", "1") != "0"
 # memory, and the up path's torch.cat([hidden, skip], 1) is read from its two producers by the same kernel (and by conv_shortcut's
 # GEMM): no concat pass either.  False = table + apply pass + materialised concat everywhere (A/B; IMH_GN_FUSE=0).
 GN_FUSE = os.environ.get("IMH_GN_FUSE", "1") != "0"
+# ... and (round 5) the table step has no launch of its own either: the consumer -- the fused conv, or the apply pass in front of a
+# Linear -- builds its sample's (scale, shift) table in its prologue from the producers' partials (imh_gemm_args.gn_part,
+# IMH_GN_TABLE_APPLY; csrc/imh_gntable.h: the same routine as the table launch, bit-identical).  False = one table launch per
+# GroupNorm (A/B; IMH_GN_TABLE_FOLD=0).
+GN_TABLE_FOLD = os.environ.get("IMH_GN_TABLE_FOLD", "1") != "0"
 
 
 class Feat:
@@ -321,9 +326,13 @@ class Transformer2DModel(nn.Module):
         B, Hh, Ww, C_ = x.shape
         L_ = Hh * Ww
         x2 = x.view(B * L_, C_)
-        tab = ctx.gn_table(f.stats(ctx, self.groups), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps, L_, descr="t2d.norm.table")
-        n = ctx.gn_apply(x.view(B, L_, C_), tab, False, descr="t2d.norm")
-        ctx.free(tab)
+        if GN_TABLE_FOLD:
+            n = ctx.gn_table_apply(x.view(B, L_, C_), GnSpec(f.stats(ctx, self.groups), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps),
+                                   False, descr="t2d.norm")
+        else:
+            tab = ctx.gn_table(f.stats(ctx, self.groups), _w(self.norm, ctx), _b(self.norm, ctx), self.groups, self.norm.eps, L_, descr="t2d.norm.table")
+            n = ctx.gn_apply(x.view(B, L_, C_), tab, False, descr="t2d.norm")
+            ctx.free(tab)
         blocks = list(self.transformer_blocks)
         ho = LN_STATS_HANDOVER and bool(blocks) and blocks[0].fused(L_)
         r = ctx.gemm(n.view(B * L_, C_), _w(self.proj_in, ctx), bias=_b(self.proj_in, ctx), descr="t2d.proj_in", stats_out=ho)
@@ -367,22 +376,27 @@ class ResnetBlock2D(nn.Module):
         Cout = self.conv1.weight.shape[0]
         want = 1 if GN_STATS_HANDOVER else 0
         srcs = [f.stats(ctx, self.groups)] + ([skip.stats(ctx, self.groups)] if skip is not None else [])
-        tab1 = ctx.gn_table(srcs, _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups, self.norm1.eps, HW, descr="res.norm1.table")
         ra = st.temb_all[:, self.temb_offset:self.temb_offset + Cout]
         fuse1 = GN_FUSE and ctx.conv_fuses_gn(M, Cout, 9 * Cin)
+        spec1 = GnSpec(srcs, _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups, self.norm1.eps)
+        # the table: built by the consumer itself (fold), or by one small launch
+        tab1 = spec1 if GN_TABLE_FOLD else ctx.gn_table(srcs, _w(self.norm1, ctx), _b(self.norm1, ctx), self.groups, self.norm1.eps, HW, descr="res.norm1.table")
         xc = None                       # the materialised concat, where something still needs it
         if fuse1:
             h = ctx.conv3x3(x, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
                             descr="res.conv1", gn_groups=want, gn=(tab1, True), x2=sk)
         else:
             xc = ctx.concat(x, sk, descr="skip.concat") if sk is not None else x
-            n = ctx.gn_apply(xc.view(B, HW, Cin), tab1, True, descr="res.norm1").view(B, Hh, Ww, Cin)
+            n = (ctx.gn_table_apply(xc.view(B, HW, Cin), tab1, True, descr="res.norm1") if GN_TABLE_FOLD
+                 else ctx.gn_apply(xc.view(B, HW, Cin), tab1, True, descr="res.norm1")).view(B, Hh, Ww, Cin)
             h = ctx.conv3x3(n, self.conv1.packed(ctx), bias=_b(self.conv1, ctx), rowadd=ra, ldra=st.temb_all.stride(0),
                             descr="res.conv1", gn_groups=want)
             ctx.free(n)
-        ctx.free(tab1)
+        if not GN_TABLE_FOLD:
+            ctx.free(tab1)
         hf = Feat(*h) if want else Feat(h)
-        tab2 = ctx.gn_table(hf.stats(ctx, self.groups), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups, self.norm2.eps, HW, descr="res.norm2.table")
+        tab2 = (GnSpec(hf.stats(ctx, self.groups), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups, self.norm2.eps) if GN_TABLE_FOLD
+                else ctx.gn_table(hf.stats(ctx, self.groups), _w(self.norm2, ctx), _b(self.norm2, ctx), self.groups, self.norm2.eps, HW, descr="res.norm2.table"))
         if self.conv_shortcut is not None:
             wsc, bsc = self.conv_shortcut.packed(ctx), _b(self.conv_shortcut, ctx)
             if sk is not None and xc is None:
@@ -399,10 +413,12 @@ class ResnetBlock2D(nn.Module):
             out = ctx.conv3x3(hf.t, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2", gn_groups=want,
                               gn=(tab2, True))
         else:
-            n = ctx.gn_apply(hf.t.view(B, HW, Cout), tab2, True, descr="res.norm2").view(B, Hh, Ww, Cout)
+            n = (ctx.gn_table_apply(hf.t.view(B, HW, Cout), tab2, True, descr="res.norm2") if GN_TABLE_FOLD
+                 else ctx.gn_apply(hf.t.view(B, HW, Cout), tab2, True, descr="res.norm2")).view(B, Hh, Ww, Cout)
             out = ctx.conv3x3(n, self.conv2.packed(ctx), bias=_b(self.conv2, ctx), residual=sc, descr="res.conv2", gn_groups=want)
             ctx.free(n)
-        ctx.free(tab2)
+        if not GN_TABLE_FOLD:
+            ctx.free(tab2)
         hf.free(ctx)
         if self.conv_shortcut is not None:
             ctx.free(sc)
@@ -760,10 +776,14 @@ class UNet2DConditionModel(nn.Module):
         # -- out --
         ctx.tag = 60
         Bh, Hh, Ww, C0 = h.t.shape
-        tab = ctx.gn_table(h.stats(ctx, cfg.norm_num_groups), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx), cfg.norm_num_groups, cfg.norm_eps,
-                           Hh * Ww, descr="conv_norm_out.table")
-        n = ctx.gn_apply(h.t.view(B, Hh * Ww, C0), tab, True, descr="conv_norm_out").view(B, Hh, Ww, C0)
-        ctx.free(tab)
+        if GN_TABLE_FOLD:
+            n = ctx.gn_table_apply(h.t.view(B, Hh * Ww, C0), GnSpec(h.stats(ctx, cfg.norm_num_groups), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx),
+                                                                    cfg.norm_num_groups, cfg.norm_eps), True, descr="conv_norm_out").view(B, Hh, Ww, C0)
+        else:
+            tab = ctx.gn_table(h.stats(ctx, cfg.norm_num_groups), _w(self.conv_norm_out, ctx), _b(self.conv_norm_out, ctx), cfg.norm_num_groups, cfg.norm_eps,
+                               Hh * Ww, descr="conv_norm_out.table")
+            n = ctx.gn_apply(h.t.view(B, Hh * Ww, C0), tab, True, descr="conv_norm_out").view(B, Hh, Ww, C0)
+            ctx.free(tab)
         h.free(ctx)
         out = ctx.conv3x3(n, self.conv_out.packed(ctx), bias=_b(self.conv_out, ctx), descr="conv_out")
         ctx.free(n)

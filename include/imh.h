@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 7
+#define IMH_ABI_VERSION 8
 
 enum imh_status {
     IMH_OK = 0,
@@ -119,6 +119,18 @@ typedef struct imh_gemm_args {
      * stays zero: the conv pads the normalised tensor); the normalised activation never exists in memory.  NULL -> plain conv. */
     const float* gn_tab;
     int32_t gn_silu;
+    /* ... or (ABI 8) the PARTIALS of the input's GroupNorm instead of a table: every workgroup then builds the (scale, shift) table of its
+     * sample in LDS in its prologue (the routine of imh_groupnorm's IMH_GN_TABLE step, bit-identical) and no table launch is needed.
+     * gn_part (+ gn_part2 for channels [gn_pC1, Cin) of a channel concat) / gn_pnblk / gn_psub / gn_pnpart (+ ...2) as imh_norm_args.partial /
+     * nblk / sub / npart; gn_gamma / gn_beta [Cin] in the activation dtype (NULL = 1 / 0), gn_groups, gn_eps > 0.  Exclusive with gn_tab. */
+    const float* gn_part;
+    const float* gn_part2;
+    const void* gn_gamma;
+    const void* gn_beta;
+    float gn_eps;
+    int32_t gn_groups, gn_pC1;
+    int32_t gn_pnblk, gn_psub, gn_pnpart;
+    int32_t gn_pnblk2, gn_psub2, gn_pnpart2;
     /* LDS-halo conv3x3 only: the input is the channel concat [X | X2] (torch.cat([hidden, skip], 1) of the up blocks) read from
      * its two producers: channels [0, Cin1) from X (pixel stride Cin1), [Cin1, Cin) from X2 (pixel stride Cin - Cin1); both
      * multiples of 64.  X2 == NULL -> one source. */
@@ -277,7 +289,8 @@ enum imh_gn_mode {
     IMH_GN_ALL = 0,     /* statistics + table + apply; `partial` = workspace of imh_groupnorm_workspace_bytes() */
     IMH_GN_STATS = 1,   /* x -> partial[B][imh_groupnorm_stats_blocks(HW, C)][C / sub][2]; sub must divide C / groups of every consumer */
     IMH_GN_TABLE = 2,   /* partial (+ partial2) -> table[B][C][2] */
-    IMH_GN_APPLY = 3    /* x, table -> y */
+    IMH_GN_APPLY = 3,   /* x, table -> y */
+    IMH_GN_TABLE_APPLY = 4   /* partial (+ partial2), x -> y in ONE launch: every workgroup builds its sample's table in LDS (ABI 8) */
 };
 typedef struct imh_norm_args {
     const void* x;

@@ -263,7 +263,8 @@ def test_conv_with_fused_groupnorm_silu(L, dtype, case):
     bias = rnd(Cout, dtype=dtype, seed=3)
     gamma, beta = rnd(Cin, dtype=dtype, seed=11) * 0.2 + 1.0, rnd(Cin, dtype=dtype, seed=12) * 0.3
     assert ctx.conv_fuses_gn(B * H * W, Cout, 9 * Cin, cfg=cfg)
-    tab = ctx.gn_table(ctx.gn_stats(x.view(B, H * W, Cin)), gamma, beta, G, 1e-5, H * W)
+    gs = ctx.gn_stats(x.view(B, H * W, Cin))
+    tab = ctx.gn_table(gs, gamma, beta, G, 1e-5, H * W)
     for silu in (True, False):
         ref = _gn_conv_ref(x, gamma, beta, w4, bias, silu)
         y = ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, silu)).view(B * H * W, Cout)
@@ -273,6 +274,12 @@ def test_conv_with_fused_groupnorm_silu(L, dtype, case):
         n = ctx.gn_apply(x.view(B, H * W, Cin), tab, silu).view(B, H, W, Cin)
         y2 = ctx.conv3x3(n, pack_conv(w4), bias=bias, cfg=cfg).view(B * H * W, Cout)
         assert torch.equal(y2, y), "in-kernel apply and the apply pass round the same values"
+        # round 5: no table launch -- the conv (and the apply pass) build the table of their sample from the partials themselves; same
+        # routine, same bits
+        from imagharmony_amd.ctx import GnSpec
+        spec = GnSpec(gs, gamma, beta, G, 1e-5)
+        assert torch.equal(ctx.conv3x3(x, pack_conv(w4), bias=bias, cfg=cfg, gn=(spec, silu)).view(B * H * W, Cout), y), "in-kernel table"
+        assert torch.equal(ctx.gn_table_apply(x.view(B, H * W, Cin), spec, silu).view(B, H, W, Cin), n), "table + apply in one launch"
         # the two workgroup forms (imh_debug_set key 5): 1 = eight do-everything waves, 2 = eight MFMA waves + four halo waves (the
         # default for fused launches); same arithmetic, same bits -- with and without the fused front end
         try:
@@ -312,6 +319,11 @@ def test_conv_over_a_two_source_concat_with_fused_groupnorm(L, dtype, case):
     assert_close(y, ref, dtype, f"two-source fused GroupNorm conv {case}", k=6.0)
     y1 = ctx.conv3x3(xc, pack_conv(w4), bias=bias, cfg=cfg, gn=(tab, True)).view(B * H * W, Cout)
     assert torch.equal(y, y1), "two sources == the materialised concat, bit for bit"
+    # the table built inside the conv from the two producers' partials (groups straddling the seam included) == the table launch's
+    from imagharmony_amd.ctx import GnSpec
+    spec = GnSpec([ga, gb], gamma, beta, G, 1e-5)
+    assert torch.equal(ctx.conv3x3(a, pack_conv(w4), bias=bias, cfg=cfg, gn=(spec, True), x2=b).view(B * H * W, Cout), y), "in-kernel two-source table"
+    assert torch.equal(ctx.gn_table_apply(xc.view(B, H * W, Cin), spec, True), ctx.gn_apply(xc.view(B, H * W, Cin), tab, True))
     # plain two-source conv (no GroupNorm) and the shortcut GEMM
     y0 = ctx.conv3x3(a, pack_conv(w4), bias=bias, cfg=cfg, x2=b)
     assert torch.equal(y0, ctx.conv3x3(xc, pack_conv(w4), bias=bias, cfg=cfg))

@@ -323,10 +323,15 @@ def test_groupnorm_statistics_handover_host_logic():
             assert (gs.sub, gs.npart, gs.C) == (10, 10 * rows, 320) and epi["gn_out"] == (1024 // rows, 1024)
             n0 = len(ctx.tags)
             ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True, stats=gs)
-            t_op, a_op = ctx._ops[-2][1], ctx._ops[-1][1]               # table, then apply: no statistics pass
-            assert [t[2] for t in ctx.tags[n0:]] == ["groupnorm.table", "groupnorm"]
+            a_op = ctx._ops[-1][1]                                      # ONE launch: the apply pass builds its sample's table itself
+            assert [t[2] for t in ctx.tags[n0:]] == ["groupnorm"]       # (no statistics pass, no table launch)
+            assert (a_op.mode, a_op.partial, a_op.nblk, a_op.sub, a_op.npart) == (L.GN_TABLE_APPLY, gs.t.data_ptr(), gs.nblk, 10, 10 * rows)
+            assert a_op.silu == 1 and a_op.groups == 32 and not a_op.table
+            tab_ = ctx.gn_table(gs, None, None, 32, 1e-5, 1024)         # the stand-alone steps are still there (consumers that share a table)
+            ctx.gn_apply(y.view(2, 1024, 320), tab_, True)
+            t_op, p_op = ctx._ops[-2][1], ctx._ops[-1][1]
             assert (t_op.mode, t_op.partial, t_op.nblk, t_op.sub, t_op.npart) == (L.GN_TABLE, gs.t.data_ptr(), gs.nblk, 10, 10 * rows)
-            assert a_op.mode == L.GN_APPLY and a_op.table == t_op.table and a_op.silu == 1
+            assert p_op.mode == L.GN_APPLY and p_op.table == t_op.table and p_op.silu == 1
         else:
             assert gs is None and epi["gn_out"] is None
             ctx.groupnorm(y.view(2, 1024, 320), None, None, 32, 1e-5, True)
@@ -351,6 +356,14 @@ def test_groupnorm_statistics_handover_host_logic():
     ctx.conv3x3(a_, w9, cfg=(7128, 160, 1), gn=(tab, True), x2=b_)
     c_op = ctx._ops[-1][1]
     assert (c_op.X, c_op.X2, c_op.Cin, c_op.Cin1, c_op.gn_tab, c_op.gn_silu) == (a_.data_ptr(), b_.data_ptr(), 960, 640, tab.data_ptr(), 1)
+    # ... or the partials themselves (round 5: the conv builds its sample's table in its prologue, no table launch)
+    from imagharmony_amd.ctx import GnSpec
+    ctx.conv3x3(a_, w9, cfg=(7128, 160, 1), gn=(GnSpec([ga, gb], None, None, 32, 1e-5), True), x2=b_)
+    s_op = ctx._ops[-1][1]
+    assert not s_op.gn_tab and (s_op.gn_part, s_op.gn_part2, s_op.gn_pC1, s_op.gn_groups, s_op.gn_silu) == (ga.t.data_ptr(), gb.t.data_ptr(), 640, 32, 1)
+    assert (s_op.gn_pnblk, s_op.gn_psub, s_op.gn_pnpart, s_op.gn_pnblk2, s_op.gn_psub2) == (ga.nblk, 10, 0, gb.nblk, 10) and abs(s_op.gn_eps - 1e-5) < 1e-12
+    with pytest.raises(L.ImhError, match="statistics"):
+        ctx.conv3x3(a_, w9, cfg=(7128, 160, 1), gn=(GnSpec([ga], None, None, 32, 1e-5), True), x2=b_)
     with pytest.raises(L.ImhError, match="LDS-halo"):
         ctx.conv3x3(a_, w9, cfg=(2464, 160, 1), gn=(tab, True), x2=b_)
     with pytest.raises(L.ImhError, match="table"):

@@ -57,6 +57,7 @@ CONFIGS = collections.OrderedDict([
     ("conv32_ws", dict(tuning={f"2048,1280,{k},1": [2464, 160, 1] for k in (5760, 11520, 17280, 23040)})),
     ("conv64_ks80", dict(tuning={f"8192,640,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("conv128_ks80", dict(tuning={f"32768,320,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640)})),
+    ("gn_table_launches", dict(gn_fold=False)),      # round 5: one gn_table launch per GroupNorm instead of the consumers building their sample's table
     ("halo_svc", dict(halo=3)),                       # imh_debug_set key 5 = 3: four halo waves for every LDS-halo conv, as SERVICE waves (they also run the weight ring)
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
@@ -104,6 +105,7 @@ def main():
         U.LN_STATS_HANDOVER = bool(c.get("ln_stats", True))
         U.GN_STATS_HANDOVER = bool(c.get("gn_stats", True))
         U.GN_FUSE = bool(c.get("gn_fuse", True))
+        U.GN_TABLE_FOLD = bool(c.get("gn_fold", True))
         AP.DUAL_WS = bool(c.get("dual_ws", False))
         AP.QKV_ONE = bool(c.get("qkv_one", True))
         AP.QKV_ONE_WIDTHS = tuple(c.get("qkv_widths", (640, 1280)))
