@@ -401,9 +401,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kg2_kernel(const GemmParams p) {
 // on LDS latency either.  One s_barrier per K tile carries both hand-overs: "tile i + 1 has landed" (producers
 // wait for it before arriving) and "tile i has been read" (consumers drain lgkmcnt before arriving), after which
 // the producers refill tile i's slot.
-#ifndef WS_ABL
-#define WS_ABL 0      // tools only: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads (timing ablations, wrong results)
-#endif
 // WS_TIMING (tools/ws_phase_probe.py only): cycle counter at the segment boundaries of the K loop; consumer wave 0 and producer wave 0
 // of workgroup 0 write their per-segment totals to p.pf_ptr instead of prefetching --
 //   consumer: [fragment reads + MFMAs] [s_waitcnt lgkmcnt(0)] [s_barrier]     producer: [LDS-DMA issue] [s_waitcnt vmcnt] [s_barrier]
@@ -517,11 +514,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
                     const unsigned char* src = ok
                         ? (const unsigned char*)p.X + (pix * p.Cin + (size_t)ct * GEMM_BK) * sizeof(T) + c * 16
                         : zero + c * 16;
-                    if (!(WS_ABL & 2)) glds16(src, dst);
+                    glds16(src, dst);
                 } else if (!CONV && k < KX && kt >= kt_x2) {
-                    if (!(WS_ABL & 2)) glds16(base2[k] + (size_t)(kt - kt_x2) * step[k], dst);
+                    glds16(base2[k] + (size_t)(kt - kt_x2) * step[k], dst);
                 } else {
-                    if (!(WS_ABL & 2)) glds16(base[k] + (size_t)kt * step[k], dst);
+                    glds16(base[k] + (size_t)kt * step[k], dst);
                 }
             }
         };
@@ -575,7 +572,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     auto rd = [&](auto KK, int slot) {
         constexpr int kk = decltype(KK)::value;
         const unsigned char* st = smem + slot * STAGE;
-        if (WS_ABL & 4) return;
 #pragma unroll
         for (int i = 0; i < FM; ++i) xf[kk][i] = *(const v8*)(st + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
 #pragma unroll
@@ -583,13 +579,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
     };
     auto mm = [&](auto KK) {
         constexpr int kk = decltype(KK)::value;
-        if (WS_ABL & 1) {                          // keep the fragment reads alive without the MFMAs
-#pragma unroll
-            for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(xf[kk][i]));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[kk][j]));
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
