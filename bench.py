@@ -609,11 +609,11 @@ def main():
             "roofline_l2_lds": {"bound": "l2->lds", "achieved": g_lds / (g_lds_ms * 1e-3) / 1e12, "unit": "TB/s",
                                 "peak": 36.5, "frac": g_lds / (g_lds_ms * 1e-3) / 1e12 / 36.5,
                                 "bytes_per_step": g_lds, "kernel": "same GEMM / conv family (dual launches excluded)",
-                                "note": "peak = the MEASURED LDS-DMA rate of L2-resident lines, every CU streaming (tools/micro/glds_rate.hip l2: "
-                                        "27.8 TB/s = 108 GB/s per CU with one workgroup per CU, 36.5 TB/s = 143 GB/s per CU with two; "
-                                        "profiles/r03_l2_lds_rate_microbench.csv), not a datasheet figure; bytes = operand tile bytes each "
-                                        "workgroup stages (lds_operand_bytes); the M = 2048 wave-specialised launches sustain 58-67 GB/s per CU "
-                                        "inside their K loops, i.e. the L2 path is NOT what bounds them (DESIGN.md 3)"},
+                                "note": "peak = the MEASURED LDS-DMA rate of L2-resident lines, every CU streaming, two workgroups per CU (tools/micro/glds_rate.hip l2: "
+                                        "36.5 TB/s = 143 GB/s per CU; 27.8 TB/s with one; profiles/r03_l2_lds_rate_microbench.csv), not a datasheet figure; bytes = "
+                                        "operand tile bytes each workgroup stages (lds_operand_bytes).  Inside their K loops the one-workgroup-per-CU launches of "
+                                        "the forward run AT this stream's rate for their bytes in flight -- 39 B/clk/CU = 90 GB/s with the 64 x 160 kernel's 84 KB "
+                                        "(tools/micro/lds_port.hip, profiles/r05_lds_port_microbench.csv); the rest of a launch is ramp (DESIGN.md 3)"},
         }
         if ip_us:
             kv_fl = 2.0 * 2 * 2 * (77 + a.ip_tokens) * 2048 * 1280          # text + ip K,V projections of one IP-active layer (CFG batch 2)

@@ -6,8 +6,9 @@ DEV="cuda:0"; dtype=torch.bfloat16
 ctx=Ctx(DEV,dtype)
 M,N,K=8192,5120,2560
 x=torch.randn(M,K,device=DEV).to(dtype); w=(torch.randn(N,K,device=DEV)*K**-0.5).to(dtype); out=torch.empty(M,N,device=DEV,dtype=dtype)
-for cfg in [(128,128,1),(256,128,1),(256,256,1),(64,64,1),(5258,320,1),(6128,320,1),(8256,256,1),(9128,320,1),(9256,320,1),
-            (2464,160,1),(24128,160,1),(23256,160,1)]:
+from imagharmony_amd import lib as L
+for cfg in [c for c in [(128,128,1),(256,128,1),(256,256,1),(64,64,1),(5258,320,1),(6128,320,1),(8256,256,1),(9128,320,1),(9256,320,1),
+                        (2464,160,1),(24128,160,1),(23256,160,1)] if L.variant_built(c)]:      # (the experimental-only variants need IMH_LIB_PATH)
     for _ in range(3): ctx.gemm(x,w,cfg=cfg,out=out)
 torch.cuda.synchronize()
 # attention too
