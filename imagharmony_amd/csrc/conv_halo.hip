@@ -392,6 +392,8 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
 #pragma unroll
                         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], xf[i], acc[i][j]);
                 }
+                // (80 accumulator registers: one tap's fragments at a time -- hoisting the three taps' reads spills 130 registers)
+                if constexpr (TPS > 1 && FM * FN >= 20) __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("" ::: "memory");
             CH_TICK(3);
@@ -469,10 +471,12 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
 // with a 2- / 3-slot weight ring
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
     const int ph = bm == 7564 ? 4 : ((bm == 7256 || bm == 7356) ? 16 : 8);
-    const bool ks = bn == 80;                    // 8 x 16 patch x 80 couts, k halves per wave pair, three taps per step, 3-slot ring (7128 x 80 only)
-    const int S = ks ? 3 : ((bm == 7328 || bm == 7356) ? 3 : (bm == 7428 ? 4 : 2));
+    // bn = 80: k halves per wave pair, three taps per step, service waves -- 7128 x 80: 8 x 16 patch, 3-slot ring; 7256 x 80: 16 x 16 patch
+    // (256 pixels x 80 couts: 44 KB of LDS-DMA per 240-MFMA step instead of 22.6 KB per 80 on 7128 x 160), 2-slot ring
+    const bool ks = bn == 80;
+    const int S = ks ? (ph == 16 ? 2 : 3) : ((bm == 7328 || bm == 7356) ? 3 : (bm == 7428 ? 4 : 2));
     if (p.stride != 1 || p.splits > 1 || p.Cin % GEMM_BK != 0 || p.K != 9 * p.Cin || (bn != 320 && bn != 160 && bn != 80) || ((S > 2 || ph == 16) && bn != 160 && !ks) ||
-        (ks && bm != 7128)) {
+        (ks && bm != 7128 && bm != 7256)) {
         set_error("conv_halo: stride-1 conv3x3 with Cin %% 64 == 0, splits == 1, bn 320 | 160 (160 only for the 3- / 4-slot rings) | 80 (7128 only) (stride=%d splits=%d Cin=%d bm=%d bn=%d)", p.stride, p.splits, p.Cin, bm, bn);
         return IMH_ERR_ARG;
     }
@@ -488,7 +492,7 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         return IMH_ERR_ARG;
     }
     int lds = 2 * (((ph + 2) * CH_HW + 7) / 8) * 8 * GEMM_ROW_BYTES + S * (ks ? 3 : 1) * bn * GEMM_ROW_BYTES + (gnf ? p.Cin * 8 : 0);
-    if (ks && lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;       // the pairs' accumulator exchange (40 KB) reuses the staging area
+    if (ks && lds < 4 * (ph / 4) * 5 * 64 * 16) lds = 4 * (ph / 4) * 5 * 64 * 16;       // the pairs' accumulator exchange (40 / 80 KB) reuses the staging area
     if (lds > 160 * 1024) { set_error("conv_halo: %d bytes of LDS (variant %d x %d, Cin=%d with the GroupNorm table)", lds, bm, bn, p.Cin); return IMH_ERR_SHAPE; }
     // the fused GroupNorm front end runs on the form with four halo waves (the input side off the MFMA waves); g_halo_mode
     // (imh_debug_set key 5, A/B): 1 forces the eight-wave form, 2 the halo-wave form for every launch
@@ -500,21 +504,27 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
 #define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) IMH_CH6(TT, FNV, FMV, SV, HV, KSV, KSV)
     // default build: every form runs with its four halo waves (the 7128 x 80 form with eight service waves).  -DIMH_EXPERIMENTAL adds the
-    // eight-wave form (g_halo_mode 1), the halo waves of the other forms as service waves (g_halo_mode 3: measured slower there -- four
-    // issuing waves pull 20-40 KB of weights per step more slowly than eight, 22.14 vs 21.86 ms per forward,
-    // profiles/r05_forward_ab_halo_svc.json), the 4 x 16 patch (7564) and the 3- / 4-slot weight rings of the 8 x 16 patch (7328 / 7428)
+    // eight-wave form (g_halo_mode 1), the halo waves of the other forms as service waves (g_halo_mode 3: four, measured slower there --
+    // four issuing waves pull 20-40 KB of weights per step more slowly than eight, 22.14 vs 21.86 ms per forward; g_halo_mode 4: eight, on
+    // the 160-cout forms that fit 128 registers: the same, 21.279 vs 21.272 ms; profiles/r05_forward_ab_halo_svc*.json), the 4 x 16 patch
+    // (7564), the 3- / 4-slot weight rings of the 8 x 16 patch (7328 / 7428) and the 16 x 16 patch x 80 couts K-split form (7256 x 80:
+    // +0.03 ms at 64 x 64, +0.47 ms at 128 x 128, profiles/r05_forward_ab_p16ks80.json; g_halo_mode 5: with four service waves)
 #ifdef IMH_EXPERIMENTAL
-#define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) { if (g_halo_mode == 3) IMH_CH6(TT, FNV, FMV, SV, 4, false, true); else IMH_CH6(TT, FNV, FMV, SV, 4, false, false); } \
+    // (g_halo_mode 4: EIGHT service waves on the forms whose MFMA waves fit 128 registers -- the 8 x 16 / 4 x 16 patch x 160 couts)
+#define IMH_CH3(TT, FNV, FMV, SV) do { if (hw4) { if (g_halo_mode == 3) IMH_CH6(TT, FNV, FMV, SV, 4, false, true); \
+            else if (g_halo_mode == 4 && FNV == 5 && FMV <= 2) IMH_CH6(TT, 5, (FMV <= 2 ? FMV : 2), SV, 8, false, true); \
+            else IMH_CH6(TT, FNV, FMV, SV, 4, false, false); } \
         else IMH_CH6(TT, FNV, FMV, SV, 0, false, false); } while (0)
 #define IMH_CH(TT) do { \
-        if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
+        if (ks && ph == 16) { if (g_halo_mode == 5) IMH_CH6(TT, 5, 4, 2, 4, true, true); else IMH_CH6(TT, 5, 4, 2, 8, true, true); } \
+        else if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
         else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
 #else
-    if (!hw4 || g_halo_mode == 3 || bm == 7564 || bm == 7328 || bm == 7428)
-        return experimental_refused("this LDS-halo conv form (eight-wave / service-wave A-B modes, variants 7564 / 7328 / 7428)");
+    if (!hw4 || g_halo_mode >= 3 || bm == 7564 || bm == 7328 || bm == 7428 || (ks && ph == 16))
+        return experimental_refused("this LDS-halo conv form (eight-wave / service-wave A-B modes, variants 7564 / 7328 / 7428 / 7256 x 80)");
 #define IMH_CH3(TT, FNV, FMV, SV) IMH_CH6(TT, FNV, FMV, SV, 4, false, false)
 #define IMH_CH(TT) do { \
         if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \

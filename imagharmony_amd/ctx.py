@@ -412,7 +412,7 @@ class Ctx:
         if bm not in self._HALO or stride != 1 or up:
             return False
         ph = 4 if bm == 7564 else (16 if bm in (7256, 7356) else 8)
-        S = 9 if bn == 80 else (3 if bm in (7328, 7356) else (4 if bm == 7428 else 2))     # (7128 x 80: three slots of three tap tiles each)
+        S = (6 if ph == 16 else 9) if bn == 80 else (3 if bm in (7328, 7356) else (4 if bm == 7428 else 2))     # (x 80: two / three slots of three tap tiles each)
         lds = 2 * (((ph + 2) * 18 + 7) // 8) * 8 * 128 + S * bn * 128 + (K // 9) * 8
         return lds <= 160 * 1024
 

@@ -21,7 +21,7 @@ GN_ALL, GN_STATS, GN_TABLE, GN_APPLY, GN_TABLE_APPLY = 0, 1, 2, 3, 4
 # variant codes / modes that only a -DIMH_EXPERIMENTAL build compiles (csrc/imh_common.h IMH_EXP_ONLY): measured, selected by no
 # tuning.json entry and no default mode.  experimental() asks the loaded library (imh_debug_set(1, 0)).
 EXP_VARIANTS = {(4064, 64), (4064, 128), (4128, 64), (5256, 320), (6128, 320), (6064, 160), (7064, 160), (256, 128), (256, 256), (22128, 160),
-                (3128, 128), (24128, 128), (9256, 320), (7564, 320), (7564, 160), (7328, 160), (7428, 160)}
+                (3128, 128), (24128, 128), (9256, 320), (7564, 320), (7564, 160), (7328, 160), (7428, 160), (7256, 80)}
 
 
 def experimental():

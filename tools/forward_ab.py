@@ -58,6 +58,11 @@ CONFIGS = collections.OrderedDict([
     ("conv64_ks80", dict(tuning={f"8192,640,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("conv128_ks80", dict(tuning={f"32768,320,{k},1": [7128, 80, 1] for k in (2880, 5760, 8640)})),
     ("gn_table_launches", dict(gn_fold=False)),      # round 5: one gn_table launch per GroupNorm instead of the consumers building their sample's table
+    ("conv64_p16ks80", dict(tuning={f"8192,640,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),      # 16 x 16 patch x 80 couts, K split
+    ("conv64_p16ks80_w4", dict(halo=5, tuning={f"8192,640,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
+    ("conv128_p16ks80", dict(tuning={f"32768,320,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640)})),
+    ("halo_svc8", dict(halo=4)),                      # eight service waves on the 8 x 16 x 160 forms (experimental build)
+    ("halo_svc8_ring3", dict(halo=4, tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("halo_svc", dict(halo=3)),                       # imh_debug_set key 5 = 3: four halo waves for every LDS-halo conv, as SERVICE waves (they also run the weight ring)
     ("qkv_dual", dict(qkv_one=False)),
     ("qkv_one", dict(qkv_one=True)),
