@@ -53,6 +53,7 @@ static GemmParams to_gemm(const imh_gemm_args* a) {
     p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.stride = a->stride; p.up = a->up;
     p.px = p.py = 1; p.tmx = p.tny = 0; p.xcd = a->xcd;
     p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
+    p.early_res = g_ws_early;
     return p;
 }
 
@@ -243,6 +244,7 @@ int imh_debug_set(int key, int value) {
     if (key == 3) { g_xattn_mode = value; return IMH_OK; }
     if (key == 4) { g_attn_mode = value; return IMH_OK; }
     if (key == 5) { g_halo_mode = value; return IMH_OK; }
+    if (key == 6) { g_ws_early = value; return IMH_OK; }      // 0: the residual rows of the wave-specialised launches fetched after the K loop (A/B)
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;
 }

@@ -15,6 +15,8 @@
 
 namespace imh {
 
+int g_ws_early = 1;     // imh_debug_set key 6 (A/B): 1 = the residual-add launches of the wave-specialised kernel fetch their residual rows before the K loop
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -616,6 +618,27 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    // The residual-add launches (to_out, ff.out, proj_out, conv2: bias + residual, nothing else) fetch the residual rows and the bias of
+    // ALL of the lane's fragments HERE, beside the producers' ring prologue: they are inputs of the launch, and the epilogue then has no
+    // load between the last MFMA and its stores (round 5: the dependent 5 MB read of 256 workgroups at once was ~1 us per launch)
+    constexpr bool RES_EARLY = LN == 0 && NC + NP <= 8;
+    constexpr int NVE = RES_EARLY ? 4 * FN : 2;
+    RawRow<T, NVE> bs_e, rr_e[RES_EARLY ? FM : 1];   // packed: half the registers of the fp32 form, held across the whole K loop
+    bool ok_e[RES_EARLY ? FM : 1];
+    bool early = false;
+    if constexpr (RES_EARLY) {
+        const int nb_e = n0 + wn * TN + (lane >> 4) * 4 * FN;
+        early = p.early_res && p.flags == 0 && !p.rowadd && p.residual && p.bias && p.splits == 1 && epilogue_fast<T, 4 * FN>(p, nb_e);
+        if (early) {
+            ldraw<T, NVE>((const T*)p.bias + nb_e, bs_e);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                ok_e[i] = m < p.M;
+                ldraw<T, NVE>((const T*)p.residual + (size_t)min(m, p.M - 1) * p.ldr + nb_e, rr_e[i]);
+            }
+        }
+    }
     __builtin_amdgcn_s_barrier();                  // tile 0 has landed
     asm volatile("" ::: "memory");
     int slot = 0;
@@ -762,17 +785,26 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
         if (p.flags == 0 && !p.rowadd && p.residual && p.splits == 1 && epilogue_fast<T, 4 * FN>(p, nb)) {
             constexpr int NV = 4 * FN;
             float bs[NV], rr[FM][NV];
-            if (p.bias) ldv<T, NV>((const T*)p.bias + nb, bs);
-            else {
-#pragma unroll
-                for (int q = 0; q < NV; ++q) bs[q] = 0.f;
-            }
             bool ok[FM];
+            if (early) {                            // fetched before the K loop
+                unraw<T, NV>(bs_e, bs);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * TM + i * 16 + (lane & 15);
-                ok[i] = m < p.M;
-                if (ok[i]) ldv<T, NV>((const T*)p.residual + (size_t)m * p.ldr + nb, rr[i]);
+                for (int i = 0; i < FM; ++i) {
+                    ok[i] = ok_e[i];
+                    unraw<T, NV>(rr_e[i], rr[i]);
+                }
+            } else {
+                if (p.bias) ldv<T, NV>((const T*)p.bias + nb, bs);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) bs[q] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                    ok[i] = m < p.M;
+                    if (ok[i]) ldv<T, NV>((const T*)p.residual + (size_t)m * p.ldr + nb, rr[i]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {

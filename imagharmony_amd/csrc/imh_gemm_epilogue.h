@@ -81,6 +81,35 @@ __device__ __forceinline__ void ldv(const T* p, float* o) {
         o[CNT - 2] = to_f32(t[0]); o[CNT - 1] = to_f32(t[1]);
     }
 }
+// the same loads kept PACKED (CNT / 2 registers instead of CNT): for operands fetched long before their use (gemm_ws's early residual)
+template <typename T, int CNT>
+struct RawRow {
+    typename Vec<T>::v8 a[CNT / 8 > 0 ? CNT / 8 : 1];
+    typename Vec<T>::v4 b;
+    typename Pk2<T>::t c;
+};
+template <typename T, int CNT>
+__device__ __forceinline__ void ldraw(const T* p, RawRow<T, CNT>& r) {
+    static_assert(CNT % 2 == 0, "vector epilogue works on even column counts");
+#pragma unroll
+    for (int q0 = 0; q0 + 8 <= CNT; q0 += 8) r.a[q0 / 8] = *(const typename Vec<T>::v8*)(p + q0);
+    constexpr int R4 = CNT / 8 * 8;
+    if constexpr (CNT % 8 >= 4) r.b = *(const typename Vec<T>::v4*)(p + R4);
+    if constexpr (CNT % 4 == 2) r.c = *(const typename Pk2<T>::t*)(p + CNT - 2);
+}
+template <typename T, int CNT>
+__device__ __forceinline__ void unraw(const RawRow<T, CNT>& r, float* o) {
+#pragma unroll
+    for (int q0 = 0; q0 + 8 <= CNT; q0 += 8)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[q0 + e] = to_f32(r.a[q0 / 8][e]);
+    constexpr int R4 = CNT / 8 * 8;
+    if constexpr (CNT % 8 >= 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[R4 + e] = to_f32(r.b[e]);
+    }
+    if constexpr (CNT % 4 == 2) { o[CNT - 2] = to_f32(r.c[0]); o[CNT - 1] = to_f32(r.c[1]); }
+}
 template <typename T, int CNT>
 __device__ __forceinline__ void stv(T* p, const float* v) {
     static_assert(CNT % 2 == 0, "vector epilogue works on even column counts");

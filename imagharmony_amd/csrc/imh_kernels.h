@@ -52,6 +52,7 @@ struct GemmParams {
     int xcd;               // requested cell shape (imh_gemm_args.xcd): 0 = cost model, 2 .. 5 = (8,1) (4,2) (2,4) (1,8)
     const void* pf_ptr;    // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
+    int early_res;         // wave-specialised kernels: fetch the residual rows / bias BEFORE the K loop (set by the launcher; g_ws_early)
 };
 
 void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits);
@@ -101,6 +102,7 @@ extern int g_xattn_mode;
 extern int g_attn_mode;
 extern int g_xcd_mode;
 extern int g_halo_mode;
+extern int g_ws_early;
 
 struct SmallAttnParams {
     const void* Q; const void* K; const void* V; void* O;

@@ -61,6 +61,7 @@ CONFIGS = collections.OrderedDict([
     ("conv64_p16ks80", dict(tuning={f"8192,640,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),      # 16 x 16 patch x 80 couts, K split
     ("conv64_p16ks80_w4", dict(halo=5, tuning={f"8192,640,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("conv128_p16ks80", dict(tuning={f"32768,320,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640)})),
+    ("res_late", dict(ws_early=0)),                   # imh_debug_set key 6 = 0: residual rows fetched after the K loop (rounds 2-4)
     ("halo_svc8", dict(halo=4)),                      # eight service waves on the 8 x 16 x 160 forms (experimental build)
     ("halo_svc8_ring3", dict(halo=4, tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("halo_svc", dict(halo=3)),                       # imh_debug_set key 5 = 3: four halo waves for every LDS-halo conv, as SERVICE waves (they also run the weight ring)
@@ -118,6 +119,7 @@ def main():
         lib.imh_debug_set(4, int(c.get("attn", 0)))
         lib.imh_debug_set(2, int(c.get("xcd", 0)))
         lib.imh_debug_set(5, int(c.get("halo", 0)))
+        lib.imh_debug_set(6, int(c.get("ws_early", 1)))
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
@@ -136,6 +138,7 @@ def main():
             lib.imh_debug_set(4, int(c.get("attn", 0)))
             lib.imh_debug_set(2, int(c.get("xcd", 0)))
             lib.imh_debug_set(5, int(c.get("halo", 0)))
+            lib.imh_debug_set(6, int(c.get("ws_early", 1)))
             ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
@@ -150,6 +153,7 @@ def main():
     lib.imh_debug_set(4, 0)
     lib.imh_debug_set(2, 0)
     lib.imh_debug_set(5, 0)
+    lib.imh_debug_set(6, 1)
     out = {}
     for n in names:
         rec, c = plans[n]
