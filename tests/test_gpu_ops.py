@@ -118,6 +118,30 @@ def test_gemm_wave_specialised_folded_layernorm_geglu(L, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2464, 160, 1), (1464, 160, 1), (24128, 160, 1), (23256, 160, 1), (128, 128, 1)])
+def test_residual_add_in_place_and_early_fetch(L, dtype, cfg):
+    """to_out / ff.out / proj_out (attention_processor.py:320-329, 453-462: linear + bias, then + residual) on the wave-specialised
+    kernels, whose residual rows and bias are fetched BEFORE the K loop (round 5): same bits as the late fetch (imh_debug_set(6, 0)),
+    also IN PLACE (Y == residual: every element is read by the lane that later stores it), ragged M, statistics epilogue unchanged"""
+    ctx = ctx_for(dtype)
+    for (M, N, K) in [(2048, 1280, 1280), (300, 640, 256), (8192, 640, 2560)]:
+        x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+        b, r = rnd(N, dtype=dtype, seed=3), rnd(M, N, dtype=dtype, seed=4)
+        ref = x.float() @ w.float().t() + b.float() + r.float()
+        y, st = ctx.gemm(x, w, bias=b, residual=r, cfg=cfg, stats_out=True)
+        assert_close(y, ref, dtype, f"bias + residual {cfg} {(M, N, K)}")
+        try:
+            assert L.load().imh_debug_set(6, 0) == 0
+            y0, st0 = ctx.gemm(x, w, bias=b, residual=r, cfg=cfg, stats_out=True)
+        finally:
+            L.load().imh_debug_set(6, 1)
+        assert torch.equal(y, y0) and torch.equal(st[0], st0[0]), "early and late residual fetch give the same bits"
+        rin = r.clone()
+        yin = ctx.gemm(x, w, bias=b, residual=rin, out=rin, cfg=cfg)
+        assert yin.data_ptr() == rin.data_ptr() and torch.equal(yin, y), "in place"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(L, dtype):
     ctx = ctx_for(dtype)
     M, N, K = 192, 256, 128
