@@ -133,7 +133,7 @@ static int do_xattn(const imh_xattn_args* a, hipStream_t s) {
     x.X = a->X; x.Wq = a->Wq; x.ln_s = a->ln_s; x.ln_c = a->ln_c; x.ln_eps = a->ln_eps;
     x.ln_stats = a->ln_s ? a->ln_stats : nullptr; x.ln_slots = a->ln_slots;
     if (x.ln_stats && (a->ln_slots <= 0 || a->C % a->ln_slots)) { set_error("cross_attention: ln_slots=%d must divide C=%d", a->ln_slots, a->C); return IMH_ERR_ARG; }
-    x.C = a->C; x.ldx = a->ldx; x.ldw = a->ldw;
+    x.C = a->C; x.ldx = a->ldx; x.ldw = a->ldw; x.split = 0;
     return xattn_launch(x, a->dtype, s);
 }
 

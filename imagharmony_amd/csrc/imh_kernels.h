@@ -95,6 +95,7 @@ struct XAttnParams {
     const float* ln_stats;   // precomputed row statistics of X (imh_lnstats.h) or null
     int ln_slots;
     int C, ldx, ldw;
+    int split;            // (set by the launcher) items per XCD dealt as two 64-query halves
 };
 int xattn_launch(const XAttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;

@@ -29,12 +29,14 @@
 
 namespace imh {
 
-int g_xattn_mode = 0;   // imh_debug_set key 3 (test / A-B only, not thread-safe): 0 auto (= 1), 1 one head per workgroup,
+int g_xattn_mode = 0;   // imh_debug_set key 3 (test / A-B only, not thread-safe): 0 auto (= 1), 1 one head per workgroup, 9 the same without half items,
                         // 2 two heads, eight do-everything waves, 3 two heads + two producer waves, 4 two heads + four producer waves;
                         // 6 / 7 / 8 = 2 / 3 / 4 without the resident key tiles
 
 
 constexpr int XQ_STAGE = 128 * 128 + 64 * 128;     // X tile (128 rows) + Wq tile (64 rows), 128 B per row
+// items per XCD dealt as two 64-query halves (host and device agree on the grid: 8 * (per + split) workgroups)
+__host__ __device__ __forceinline__ int xattn_split(const int per) { return (per > 32 && per < 64) ? per - 32 : 0; }
 
 // XA_TIMING (tools/xattn_phase_probe.py only): every workgroup stamps entry / end of the to_q K loop / end of the key loops / exit on the
 // chip-wide 100 MHz counter into p.pf_ptr[item * 4 ..] (instead of prefetching) -- the launch as a time line per workgroup
@@ -60,11 +62,24 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     const int gx = (p.Lq + 32 * NW - 1) / (32 * NW);
     const int items = gx * p.H * p.B;
     const int per = (items + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    // Round 5: when an XCD's 32 CUs get between 32 and 64 items (the C = 1280 / L = 1024 layers at UNet batch 2: 40), the items beyond
+    // the 32nd are dealt as HALVES (64 queries, two active waves) -- the launch is as long as its most loaded CU's operand stream
+    // (r05_xattn_phase_probe.txt), and a CU with one item + one half pulls 819 KB where a CU with two items pulls 982 KB
+    const int split = xp.split;                // xattn_split(per), or 0 (imh_debug_set(3, 9): A/B)
+    const int jx = blockIdx.x >> 3;
+    int item, qoff = 0, nq = 32 * NW;
+    if (jx < per - split) item = (blockIdx.x & 7) * per + jx;
+    else {
+        const int k = jx - (per - split);
+        if (k >= 2 * split) return;
+        item = (blockIdx.x & 7) * per + (per - split) + (k >> 1);
+        qoff = (k & 1) * 64; nq = 64;
+    }
+    if (item >= items) return;
     const int hb = item / gx, qblk = item - hb * gx;
     const int b = hb / p.H, h = hb - b * p.H;
-    const int q0 = qblk * (32 * NW);
+    const int q0 = qblk * (32 * NW) + qoff;
+    const bool act = wave * 32 < nq;           // (wave-uniform) the waves of a half item beyond its 64 queries only help staging the weights
 #if XA_TIMING
     const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -88,8 +103,10 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
     auto stage = [&](int buf, int kt) {
         unsigned char* xs = smem + buf * XQ_STAGE;
         unsigned char* ws = xs + 128 * 128;
+        if (act) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(xsrc[i] + (size_t)kt * 128, xs + (wave * 32 + i * 8) * 128);
+            for (int i = 0; i < 4; ++i) glds16(xsrc[i] + (size_t)kt * 128, xs + (wave * 32 + i * 8) * 128);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(wsrc[i] + (size_t)kt * 128, ws + (wave * 16 + i * 8) * 128);
     };
@@ -120,17 +137,19 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
         asm volatile("" ::: "memory");
         if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
         const unsigned char* sb = smem + (kt & 1) * XQ_STAGE;
-        v8 xf[4], wf[2][4];
+        if (act) {
+            v8 xf[4], wf[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            xf[ks] = *(const v8*)(sb + xoff[ks]);
+            for (int ks = 0; ks < 4; ++ks) {
+                xf[ks] = *(const v8*)(sb + xoff[ks]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) wf[dt][ks] = *(const v8*)(sb + woff[dt][ks]);
+                for (int dt = 0; dt < 2; ++dt) wf[dt][ks] = *(const v8*)(sb + woff[dt][ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
         asm volatile("" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -169,11 +188,11 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 #if XA_TIMING
     const unsigned long long ts_keys = __builtin_amdgcn_s_memrealtime();
 #endif
-    attn_store<T, NW>(p, smem, fin, b, h, q0, wave, lane);
+    if (act) attn_store<T, NW>(p, smem, fin, b, h, q0, wave, lane);
 #if XA_TIMING
     if (tid == 0 && p.pf_ptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)item * 4;
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)blockIdx.x * 4;
         dbg[0] = ts_entry; dbg[1] = ts_proj; dbg[2] = ts_keys; dbg[3] = __builtin_amdgcn_s_memrealtime();
     }
 #else
@@ -498,12 +517,15 @@ int xattn_launch(const XAttnParams& xp, int dtype, hipStream_t stream) {
     // operands (profiles/r03_attn_ab.json vs r03_forward_ab_*.json)
     int mode = g_xattn_mode;
     if (mode == 0) mode = 1;
-    if ((p.H & 1) || mode == 1) {
+    if ((p.H & 1) || mode == 1 || mode == 9) {
         const int items = ((p.Lq + 127) / 128) * p.H * p.B;
-        dim3 grid(8 * ((items + 7) / 8));
+        const int per = (items + 7) / 8;
+        XAttnParams xq = xp;
+        xq.split = g_xattn_mode == 9 ? 0 : xattn_split(per);          // (mode 9, A/B: whole items only)
+        dim3 grid(8 * (per + xq.split));
 #define IMH_XA1(TT, NPV) do { \
-            if (!xp.ln_s) hipLaunchKernelGGL((xattn_kernel<TT, NPV, false>), grid, dim3(256), 0, stream, xp); \
-            else hipLaunchKernelGGL((xattn_kernel<TT, NPV, true>), grid, dim3(256), 0, stream, xp); } while (0)
+            if (!xp.ln_s) hipLaunchKernelGGL((xattn_kernel<TT, NPV, false>), grid, dim3(256), 0, stream, xq); \
+            else hipLaunchKernelGGL((xattn_kernel<TT, NPV, true>), grid, dim3(256), 0, stream, xq); } while (0)
 #define IMH_XA(TT) do { if (p.K2) IMH_XA1(TT, 2); else IMH_XA1(TT, 1); } while (0)
         if (dtype == IMH_DT_BF16) IMH_XA(bf16_t);
         else IMH_XA(f16_t);

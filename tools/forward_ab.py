@@ -89,7 +89,7 @@ CONFIGS = collections.OrderedDict([
     ("base_again", dict()),                            # position control: the same configuration twice in one interleaved round
     ("xcd81", dict(xcd=2)), ("xcd42", dict(xcd=3)), ("xcd24", dict(xcd=4)), ("xcd18", dict(xcd=5)),
     ("xcd_m2", dict(xcd=6)), ("xcd_m3", dict(xcd=7)),   # the cost model restricted to (8,1) (4,2) / to (8,1) (4,2) (2,4)
-    ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)),
+    ("x1", dict(xattn=1)), ("x3", dict(xattn=3)), ("x4", dict(xattn=4)), ("x_whole_items", dict(xattn=9)),
 ])
 
 
