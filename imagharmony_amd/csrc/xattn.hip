@@ -43,6 +43,9 @@ __host__ __device__ __forceinline__ int xattn_split(const int per) { return (per
 #ifndef XA_TIMING
 #define XA_TIMING 0
 #endif
+#ifndef XA_ABL
+#define XA_ABL 0       // tools/xattn_phase_probe.py only (wrong results by design): 1 no MFMAs, 2 no fragment reads either, 4 no LDS-DMA in the loop, 8 no barrier
+#endif
 
 // LNQ: norm2 folded into to_q, row statistics handed over (xp.ln_stats)
 template <typename T, int NPASS, bool LNQ>
@@ -131,13 +134,16 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
         const f32x2s mr = merge_row_stats(xp.ln_stats, b * p.Lq + min(q0 + wave * 32 + (lane & 31), p.Lq - 1), xp.ln_slots, xp.C, xp.ln_eps);
         st_s = mr[0]; st_q = mr[1];
     }
+    // (Round 5, measured and not adopted -- NEGATIVE_RESULTS.md: a three-slot ring with counted vmcnt, the same with tile kt + 1's fragments
+    // read under tile kt's MFMAs, and two producer waves owning the LDS-DMA stream.  Alone, this loop's LDS-DMA half takes 8.3 us and its
+    // reads + MFMAs half 7.4 of the 10.7: r05_xattn_loop_ablation.txt.)
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile kt has landed
-        __builtin_amdgcn_s_barrier();                         // ... everyone's has; tile kt-1 is fully consumed
+        if (!(XA_ABL & 8)) __builtin_amdgcn_s_barrier();      // ... everyone's has; tile kt-1 is fully consumed
         asm volatile("" ::: "memory");
-        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nkt && !(XA_ABL & 4)) stage((kt + 1) & 1, kt + 1);
         const unsigned char* sb = smem + (kt & 1) * XQ_STAGE;
-        if (act) {
+        if (act && !(XA_ABL & 2)) {
             v8 xf[4], wf[2][4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -145,10 +151,15 @@ __global__ __launch_bounds__(256, NPASS == 1 ? 3 : 2) void xattn_kernel(const XA
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) wf[dt][ks] = *(const v8*)(sb + woff[dt][ks]);
             }
+            if (XA_ABL & 1) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(xf[ks]), "v"(wf[0][ks]), "v"(wf[1][ks]));
+            } else {
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) qa[dt] = mfma32(wf[dt][ks], xf[ks], qa[dt]);
+            }
         }
         asm volatile("" ::: "memory");
     }

@@ -29,7 +29,7 @@ constexpr int SLOT = 28 * 1024;      // bytes per slot (the 64 x 160 kernel's st
 constexpr int XWIN = 160 * 1024;     // token-row window of an m tile (64 rows x 1280 k x 2 B)
 constexpr int WWIN = 400 * 1024;     // weight window of an n tile (160 rows x 1280 k x 2 B)
 
-template <int NP, int NG, int NR, int NV, int NM>
+template <int NP, int NG, int NR, int NV, int NM, int PM = 0, bool IL = false>
 __global__ __launch_bounds__(64 * (4 + NP), 1) void k(const unsigned char* xsrc, const unsigned char* wsrc, int tiles,
                                                       unsigned long long* cyc, float* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,6 +54,60 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void k(const unsigned char* xsrc,
             xo += 8 * 1024; if (xo + 8 * 1024 > XWIN) xo = 0;
             wo += WSTEP; if (wo + WSTEP > WWIN) wo = 0;
         };
+        if constexpr (PM >= 1 && NG > 0) {
+            // ---- the same stream through VGPRs: global_load_dwordx4 (D = PM + 2 tiles in flight) -> ds_write_b128 into the slot
+            constexpr int D = PM + 2;
+            u32x4 rg[D][NG];
+            auto pload = [&](const int set) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int piece = g * NP + pw;
+                    const unsigned char* src = piece < 8 ? xw + xo + piece * 1024 : ww + wo + (piece - 8) * 1024;
+                    rg[set][g] = *(const u32x4*)(src + lane * 16);
+                }
+                xo += 8 * 1024; if (xo + 8 * 1024 > XWIN) xo = 0;
+                wo += WSTEP; if (wo + WSTEP > WWIN) wo = 0;
+            };
+            auto pwrite = [&](const int set, int slot) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) *(u32x4*)(smem + slot * SLOT + (g * NP + pw) * 1024 + lane * 16) = rg[set][g];
+            };
+#pragma unroll
+            for (int i = 0; i < D; ++i) pload(i);
+            wait_vmcnt<(D - 1) * NG>(); pwrite(0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int slot = 1;
+            for (int t = 0; t < tiles; t += D) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {          // load tile t + i + D into the set tile t + i left, write tile t + i + 1
+                    if constexpr (IL) {                // piece by piece: ds_write of tile t + i + 1 between the loads of tile t + i + D
+                        wait_vmcnt<(D - 2) * NG>();    // (tile t + i + 1 has landed: the D - 2 younger tiles may be in flight)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const int piece = g * NP + pw;
+                            const unsigned char* src = piece < 8 ? xw + xo + piece * 1024 : ww + wo + (piece - 8) * 1024;
+                            rg[i][g] = *(const u32x4*)(src + lane * 16);
+                            __builtin_amdgcn_sched_barrier(0);
+                            *(u32x4*)(smem + slot * SLOT + piece * 1024 + lane * 16) = rg[(i + 1) % D][g];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        xo += 8 * 1024; if (xo + 8 * 1024 > XWIN) xo = 0;
+                        wo += WSTEP; if (wo + WSTEP > WWIN) wo = 0;
+                    } else {
+                    pload(i);
+                    wait_vmcnt<(D - 1) * NG>();
+                    pwrite((i + 1) % D, slot);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (++slot == S) slot = 0;
+                }
+            }
+            wait_vmcnt<0>();
+            return;
+        }
         if (NG > 0) {
 #pragma unroll
             for (int s = 0; s < S - 1; ++s) issue(s, s);
@@ -142,10 +196,10 @@ __global__ __launch_bounds__(64 * (4 + NP), 1) void k(const unsigned char* xsrc,
 
 struct Res { double cyc_med, ns; };
 
-template <int NP, int NG, int NR, int NV, int NM>
+template <int NP, int NG, int NR, int NV, int NM, int PM = 0, bool IL = false>
 Res run(const unsigned char* x, const unsigned char* w, unsigned long long* cyc, float* sink) {
     const int tiles = 3000;
-    auto kern = k<NP, NG, NR, NV, NM>;
+    auto kern = k<NP, NG, NR, NV, NM, PM, IL>;
     const int threads = 64 * (4 + NP);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S * SLOT);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -192,5 +246,20 @@ int main() {
     ROW("proposed, 4 producers", 4, 2, 4, 5, 20);
     ROW("proposed, 2 producers", 2, 4, 4, 5, 20);
     ROW("proposed without mfma", 2, 4, 4, 5, 0);
+    // ---- the LDS-DMA stream replaced by producer-wave global_load_dwordx4 -> VGPR -> ds_write_b128 (same bytes, same ring)
+#define ROWV(name, NP, NG, NR, NM, PM, IL) do { Res r = run<NP, NG, NR, 0, NM, PM, IL>(x, w, cyc, sink); \
+    printf("%s, %d, %d, %d, %d, %d, %.0f, %.0f\n", name, NP, NP * NG, 4 * NR, 0, NM, r.cyc_med, r.ns); fflush(stdout); } while (0)
+    ROWV("via vgpr (3 tiles in flight): load + ds_write only (28 KB)", 4, 7, 0, 0, 1, false);
+    ROWV("via vgpr (3): 8 KB only", 4, 2, 0, 0, 1, false);
+    ROWV("via vgpr (3) + reads + mfma (= current mix)", 4, 7, 14, 20, 1, false);
+    ROWV("via vgpr (6 tiles in flight): load + ds_write only (28 KB)", 4, 7, 0, 0, 4, false);
+    ROWV("via vgpr (6) + reads + mfma", 4, 7, 14, 20, 4, false);
+    ROWV("via vgpr (4), loads and writes interleaved: 28 KB only", 4, 7, 0, 0, 2, true);
+    ROWV("via vgpr (4), interleaved + reads + mfma", 4, 7, 14, 20, 2, true);
+    ROWV("via vgpr (6), interleaved: 28 KB only", 4, 7, 0, 0, 4, true);
+    ROWV("via vgpr (6), interleaved: 8 KB only", 4, 2, 0, 0, 4, true);
+    ROWV("via vgpr (6), interleaved + reads", 4, 7, 14, 0, 4, true);
+    ROWV("via vgpr (6), interleaved + reads + mfma", 4, 7, 14, 20, 4, true);
+    ROWV("via vgpr (6), interleaved, seven producers + reads + mfma", 7, 4, 14, 20, 4, true);
     return 0;
 }
