@@ -112,7 +112,7 @@ static int do_attn(const imh_attn_args* a, hipStream_t s) {
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.Lk_pad = a->Lk_pad; p.Lk2 = a->Lk2; p.Lk2_pad = a->Lk2_pad;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldk2 = a->ldk2; p.ldvt2 = a->ldvt2; p.ldo = a->ldo;
     p.scale = a->scale; p.scale2 = a->scale2; p.scale2_tab = a->scale2_tab; p.step = a->step;
-    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes;
+    p.pf_ptr = a->pf_ptr; p.pf_bytes = a->pf_bytes; p.split = 0; p.defer_log2 = 0.f;
     return attention_launch(p, a->dtype, s);
 }
 

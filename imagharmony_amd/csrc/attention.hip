@@ -22,7 +22,8 @@ namespace imh {
 int g_attn_force_nw = 0;   // retired tuning knob (imh_debug_set key 0): only the 4-wave workgroup is built
 int g_attn_mode = 0;       // imh_debug_set key 4 (tests / A-B only; read at launch or capture time, not thread-safe): 0 auto, 1 in-order key loop
                            // (attn_core), 2 software-pipelined key loop (attn_core_pipe; one key set) with the textbook running maximum, 3 the same
-                           // with the deferred maximum, 5 key-split workgroups (attn_ks_kernel, deferred maximum), 6 the same, textbook maximum
+                           // with the deferred maximum, 5 key-split workgroups (attn_ks_kernel, deferred maximum), 6 the same, textbook maximum,
+                           // 7 = 3 with whole items only (no key-quarter workgroups)
 constexpr float ATT_DEFER_LOG2 = 8.0f;
 
 // NW waves per workgroup (32 queries each); the launcher uses NW = 4.
@@ -99,11 +100,108 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
     const int gx = (p.Lq + 32 * NW - 1) / (32 * NW);
     const int items = gx * p.H * p.B;
     const int per = (items + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+    // Round 5: when an XCD's item count is not a multiple of its 32 CUs (L = 1024 at UNet batch 2: 40; L = 4096: 80) the left-over items are
+    // not run as 4-wave workgroups on a few CUs -- those CUs then carry two waves per SIMD for the whole launch (21.4 us against 14.6,
+    // r05_attn_wg_timeline.txt) -- but as 4 * split QUARTER workgroups, one per CU: (item, 32 queries) with the four waves on the four
+    // quarters of the keys, merged through LDS.  Every SIMD then carries 1 + 1/4 units of work.
+    const int split = p.split;
+    const int jx = blockIdx.x >> 3;
+    int item, qg = -1;
+    if (jx < per - split) item = (blockIdx.x & 7) * per + jx;
+    else {
+        const int k = jx - (per - split);
+        if (k >= 4 * split) return;
+        item = (blockIdx.x & 7) * per + (per - split) + (k >> 2);
+        qg = k & 3;
+    }
+    if (item >= items) return;
     const int hb = item / gx, qblk = item - hb * gx;
     const int b = hb / p.H, h = hb - b * p.H;
     const int q0 = qblk * (32 * NW);
+#if ATT_TIMING == 2
+    const unsigned long long ts_entry_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (qg >= 0) {
+        // ---- quarter role: wave w runs the plain in-order tile over keys [w * Lk / 4, +Lk / 4) for queries q0 + 32 qg .. + 31, from a
+        //      wave-private one-slot K / V^T tile (no workgroup barrier in the loop: the co-resident whole item's wave on this SIMD fills
+        //      the load latency); the launcher guarantees Lk % 256 == 0 and Lq % 128 == 0
+        const float c = p.scale * LOG2E;
+        unsigned char* my = smem + wave * (2 * ATT_TILE_BYTES);
+        v8 qf[4];
+        {
+            const T* qrow = (const T*)p.Q + ((size_t)b * p.Lq + q0 + qg * 32 + l32) * p.ldq + h * 64 + hi * 8;
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) qf[sd] = *(const v8*)(qrow + sd * 16);
+        }
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = NEG_BIG, l_run = 0.f;
+        const int ntq = (p.Lk / ATT_KV) >> 2;
+        for (int t = 0; t < ntq; ++t) {
+            const int tile = wave * ntq + t;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                attn_stage_tile<T>((const T*)p.K, (const T*)p.Vt, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, my, my + ATT_TILE_BYTES, w, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the Q fragments too, at t = 0)
+            attn_tile<T>(my, my + ATT_TILE_BYTES, qf, lane, tile * ATT_KV, p.Lk, c, o, m_run, l_run);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the slot are done before it is staged again
+        }
+        // merge the four partial (m, l, O) of every query row: waves 1..3 park theirs in their (dead) slots, wave 0 combines in a fixed
+        // order -- m = max m_i, a_i = 2^((m_i - m) c), O = sum O_i a_i / sum l_i a_i -- and stores
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (wave > 0) {
+            float* w = (float*)my;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) w[(dt * 16 + r) * 64 + lane] = o[dt][r];
+            w[32 * 64 + lane] = m_run;
+            w[33 * 64 + lane] = l_tot;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave == 0) {
+            float mi[4], li[4];
+            mi[0] = m_run; li[0] = l_tot;
+#pragma unroll
+            for (int g = 1; g < 4; ++g) {
+                const float* w = (const float*)(smem + g * (2 * ATT_TILE_BYTES));
+                mi[g] = w[32 * 64 + lane]; li[g] = w[33 * 64 + lane];
+            }
+            const float m = fmaxf(fmaxf(mi[0], mi[1]), fmaxf(mi[2], mi[3]));
+            float ai[4], den = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { ai[g] = __builtin_amdgcn_exp2f((mi[g] - m) * c); den += li[g] * ai[g]; }
+            const float inv = 1.0f / den;
+            f32x16 fin[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = o[dt][r] * ai[0];
+#pragma unroll
+                    for (int g = 1; g < 4; ++g) v += ((const float*)(smem + g * (2 * ATT_TILE_BYTES)))[(dt * 16 + r) * 64 + lane] * ai[g];
+                    fin[dt][r] = v * inv;
+                }
+            attn_store<T, 1>(p, smem, fin, b, h, q0 + qg * 32, 0, lane);      // (wave 0's own slot: rows 0..31 as staging rows)
+        }
+#if ATT_TIMING == 2
+        if (tid == 0 && p.pf_ptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)blockIdx.x * 4;
+            dbg[0] = ts_entry_; dbg[1] = __builtin_amdgcn_s_memrealtime(); dbg[2] = hwid; dbg[3] = (blockIdx.x & 7) | 0x100;
+        }
+#else
+        if (qg == 0) tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+#endif
+        return;
+    }
     v8 qf[4];
     {
 #pragma unroll
@@ -123,7 +221,17 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
     f32x16 fin[2];
     attn_core_pipe<T>(p, smem, qf, b, h, wave, lane, fin);
     attn_store<T, NW>(p, qs, fin, b, h, q0, wave, lane);
+#if ATT_TIMING == 2     // tools/attn_phase_probe.py wg: every workgroup stamps (entry, exit) on the chip-wide 100 MHz counter + its XCC / CU id
+    if (tid == 0 && p.pf_ptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + (size_t)blockIdx.x * 4;
+        dbg[0] = ts_entry_; dbg[1] = __builtin_amdgcn_s_memrealtime(); dbg[2] = hwid; dbg[3] = blockIdx.x & 7;
+    }
+#else
     tail_prefetch(p.pf_ptr, p.pf_bytes, item, items, tid, 64 * NW);
+#endif
 }
 
 // Key-split self-attention (imh_attn_core.h attn_core_ks): one workgroup = (batch, head, 128 queries) = 8 waves = 2 key halves x 4
@@ -352,14 +460,20 @@ int attention_launch(const AttnParams& p, int dtype, hipStream_t stream) {
         return check_launch("attn_ks_kernel");
 #endif
     }
-    if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || g_attn_mode == 3 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
+    if (!p.K2 && p.Lk % ATT_KV == 0 && (g_attn_mode == 2 || g_attn_mode == 3 || g_attn_mode == 7 || (g_attn_mode == 0 && p.Lk >= 4 * ATT_KV))) {
         const int lds = ATT_PIPE_STAGES * 2 * ATT_TILE_BYTES;
         AttnParams q = p;
         q.defer_log2 = g_attn_mode == 2 ? 0.0f : ATT_DEFER_LOG2;
+        // items beyond one per CU as key-quarter workgroups (attn_pipe_kernel); imh_debug_set(4, 7) = whole items only (A/B)
+        const int per = (items + 7) / 8;
+        // (per % 32 items per XCD are left over after whole rounds of one item per CU: 8 of 40 at L = 1024, 16 of 80 at L = 4096 (UNet batch 2);
+        // up to 16 -- a quarter workgroup reads its head's whole K / V^T for 32 queries, 4 x the bytes per query of a whole item)
+        q.split = (g_attn_mode != 7 && per > 32 && per % 32 != 0 && per % 32 <= 16 && p.Lq % 128 == 0 && p.Lk % (4 * ATT_KV) == 0) ? per % 32 : 0;
+        dim3 gridp(8 * (per + 3 * q.split));
         if (dtype == IMH_DT_BF16) { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<bf16_t>, lds);
-                                    hipLaunchKernelGGL((attn_pipe_kernel<bf16_t>), grid, dim3(256), lds, stream, q); }
+                                    hipLaunchKernelGGL((attn_pipe_kernel<bf16_t>), gridp, dim3(256), lds, stream, q); }
         else { static DynLdsOnce once; once.ensure((const void*)attn_pipe_kernel<f16_t>, lds);
-               hipLaunchKernelGGL((attn_pipe_kernel<f16_t>), grid, dim3(256), lds, stream, q); }
+               hipLaunchKernelGGL((attn_pipe_kernel<f16_t>), gridp, dim3(256), lds, stream, q); }
         return check_launch("attn_pipe_kernel");
     }
 #define IMH_ATT_LAUNCH(TT, NWV) do { if (p.K2) hipLaunchKernelGGL((attn_kernel<TT, NWV, 2>), grid, dim3(64 * NWV), 0, stream, p); \

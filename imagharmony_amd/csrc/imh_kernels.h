@@ -79,6 +79,7 @@ struct AttnParams {
     const int* step;
     const void* pf_ptr;       // next kernel's weights (tail prefetch), or null
     unsigned pf_bytes;
+    int split;                // pipelined kernel: items per XCD dealt as four key-quarter workgroups of 32 queries (set by the launcher)
     float defer_log2;         // pipelined key loop: keep the running maximum while no row's maximum grew by more than 2^this (set by the launcher)
 };
 int attention_launch(const AttnParams& p, int dtype, hipStream_t stream);

@@ -482,6 +482,41 @@ def test_attention_creeping_maximum(L, dtype, mode):
         L.load().imh_debug_set(4, 0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq", [(2, 20, 1024), (1, 33, 1024), (1, 43, 768), (2, 10, 4096)])
+def test_attention_key_quarter_workgroups(L, dtype, B, H, Lq):
+    """the pipelined kernel deals the items an XCD has beyond whole rounds of one per CU (per % 32 of them, up to 16: 8 of 40 at the
+    L = 1024 layers of UNet batch 2, 16 of 80 at L = 4096; 1 of 33; 1 of 33 with a ragged last XCD) as workgroups of 32 queries whose
+    four waves take the four quarters of the keys and merge in LDS: against the fp32 reference, bitwise repeatable, and within rounding
+    of the whole-item launch (imh_debug_set(4, 7)); plus the creeping-maximum rows (a maximum that moves in every tile and every quarter)"""
+    ctx = ctx_for(dtype)
+    C_ = H * 64
+    _attention_self_case(L, dtype, B, H, Lq)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    q = torch.randn(B, Lq, H, 64, generator=g)
+    k = torch.randn(B, Lq, H, 64, generator=g) * 0.2
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    q = q + 8.0 * u
+    k = k + ((torch.arange(Lq) // 64).float() * (3.0 * 16 / (Lq // 64) / (0.125 * 8.0 * 1.4427)))[None, :, None, None] * u
+    qk = torch.cat([q.reshape(B * Lq, C_), k.reshape(B * Lq, C_)], 1).to(dtype).to(DEV)
+    v = rnd(B, Lq, C_, dtype=dtype, seed=2)
+    vt = make_vt(v, Lq)
+    ref = sdpa_ref(qk[:, :C_].reshape(B, Lq, C_), qk[:, C_:].reshape(B, Lq, C_), v, H)
+    outs = []
+    for mode in (0, 7):
+        assert L.load().imh_debug_set(4, mode) == 0
+        try:
+            out = ctx.new(B * Lq, C_)
+            ctx.attention(qk[:, :C_], qk[:, C_:], vt, out, B, H, Lq, Lq, Lq, 2 * C_, 2 * C_, B * Lq, C_, 0.125)
+            assert_close(out.view(B, Lq, C_), ref, dtype, f"key-quarter workgroups, creeping maximum, mode {mode}", k=6.0)
+            outs.append(out)
+        finally:
+            L.load().imh_debug_set(4, 0)
+    assert not torch.equal(outs[0], outs[1]), "the two launches agree bit for bit: the key-quarter workgroups did not run"
+    from conftest import rel_rms
+    assert rel_rms(outs[0], outs[1]) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+
+
 def _spiked_case(L):
     dtype = torch.bfloat16
     ctx = ctx_for(dtype)

@@ -34,6 +34,7 @@ CONFIGS = collections.OrderedDict([
     ("attn1", dict(attn=1)),
     ("attn3", dict(attn=3)),
     ("attn5", dict(attn=5)),
+    ("attn_whole_items", dict(attn=7)),      # the pipelined kernel without the key-quarter workgroups
     # LayerNorm statistics from stand-alone row-statistics launches instead of the producers' epilogues
     ("ln_rowstats", dict(ln_stats=False)),
     ("gn_off", dict(gn_stats=False)),
