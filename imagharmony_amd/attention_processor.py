@@ -170,8 +170,10 @@ class AttnProcessor2_0(nn.Module):
             f3 = _cached(attn, "_imh_ln_qkv3", key, lambda: fold_ln(
                 torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach(), attn.to_v.weight.detach()], 0), norm, ctx))
             vt = ctx.new(C_, B * L_)
-            cfg3 = ctx.tuning.get((B * L_, 3 * C_, C_, 0, 1))         # (a table entry must be a wave-specialised bn = 160 variant)
-            if cfg3 is None or cfg3[0] not in (23256, 24128, 2464, 1464) or cfg3[1] != 160 or cfg3[2] != 1 or (B * L_) % 256:
+            cfg3 = ctx.tuning.get((B * L_, 3 * C_, C_, 0, 1))         # (a table entry must be a wave-specialised bn = 160 variant or 23256 x 128)
+            ok3 = cfg3 is not None and cfg3[2] == 1 and (B * L_) % 256 == 0 and (
+                (cfg3[0] in (23256, 24128, 2464, 1464) and cfg3[1] == 160) or (tuple(cfg3[:2]) == (23256, 128) and C_ % 128 == 0))
+            if not ok3:
                 cfg3 = (23256, 160, 1)
             qk = ctx.gemm(x, f3[0], flags=L.GF_LN_ROW, ln=(f3[1], f3[2], norm.eps, ln_stats), cfg=tuple(cfg3), yt=(vt, 2 * C_),
                           descr="self.to_qkv")

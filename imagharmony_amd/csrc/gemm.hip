@@ -438,7 +438,7 @@ void gemm_pick_config(int M, int N, int K, int* bm, int* bn, int* splits) {
 int gemm_stats_slot_width(int bm, int bn) {
     if ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return bn / 2;          // plain tiles: 2 x 2 waves
     if ((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128) && bn == 160) return 80;   // wave-specialised, CN = 2
-    if (bm == 24128 && bn == 128) return 64;
+    if ((bm == 24128 || bm == 23256) && bn == 128) return 64;
     return 0;
 }
 
@@ -516,11 +516,12 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
         if (!p.X2) p.Cin1 = conv ? p.Cin : p.K;
         if (p.Yt) {      // transposed V^T store of the columns >= yt_col0: the lean LN epilogue of the wave-specialised kernels
             const int rows = bm == 23256 ? 256 : (bm == 24128 || bm == 22128 ? 128 : 64);
-            if (!ws || bn != 160 || conv || p.flags != GF_LN_ROW || p.residual || p.rowadd || p.splits > 1 || p.M % rows || p.N % 160 ||
-                p.yt_col0 <= 0 || p.yt_col0 >= p.N || p.yt_col0 % 160 || (p.ldyt & 7) || p.ldyt < p.M || (p.ldy & 7)) {
-                set_error("gemm: Yt (transposed V^T store) needs a wave-specialised bn = 160 variant, flags == IMH_GF_LN_ROW only, no residual / "
-                          "row-add / split-K, whole tiles (M %% %d, N %% 160), 0 < yt_col0 < N a multiple of 160, ldyt >= M a multiple of 8 "
-                          "(bm=%d M=%d N=%d yt_col0=%d ldyt=%d flags=%d)", rows, bm, p.M, p.N, p.yt_col0, p.ldyt, p.flags);
+            const bool wide = bn == 160 || (bm == 23256 && bn == 128);
+            if (!ws || !wide || conv || p.flags != GF_LN_ROW || p.residual || p.rowadd || p.splits > 1 || p.M % rows || p.N % bn ||
+                p.yt_col0 <= 0 || p.yt_col0 >= p.N || p.yt_col0 % bn || (p.ldyt & 7) || p.ldyt < p.M || (p.ldy & 7)) {
+                set_error("gemm: Yt (transposed V^T store) needs a wave-specialised bn = 160 variant or 23256 x 128, flags == IMH_GF_LN_ROW only, no residual / "
+                          "row-add / split-K, whole tiles (M %% %d, N %% bn), 0 < yt_col0 < N a multiple of bn, ldyt >= M a multiple of 8 "
+                          "(bm=%d bn=%d M=%d N=%d yt_col0=%d ldyt=%d flags=%d)", rows, bm, bn, p.M, p.N, p.yt_col0, p.ldyt, p.flags);
                 return IMH_ERR_ARG;
             }
         }

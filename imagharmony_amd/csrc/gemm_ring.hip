@@ -982,6 +982,8 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
     IMH_EXP_ONLY(if (bm == 22128 && bn == 160) return launch_ws<T, 128, 160, 2, 2, 2, 2, CONV, 2>(p, stream);)
     // 256 x 160, eight consumer waves (4 x 2, 64 x 80 each) + four producers, 3 stages (156 KB): N = 10240 -> 512 tiles
     if (bm == 23256 && bn == 160) return launch_ws<T, 256, 160, 4, 2, 3, 4, CONV>(p, stream);
+    // 256 x 128 (64 x 64 wave tiles): N = 3840 -> 240 tiles where 256 x 160 makes 192 -- the one-launch [Q|K|V] of the L = 1024 layers (round 5)
+    if (bm == 23256 && bn == 128) return launch_ws<T, 256, 128, 4, 2, 3, 4, CONV>(p, stream);
     IMH_EXP_ONLY(if (bm == 3128 && bn == 128) return launch_kg2<T, 128, 128, CONV>(p, stream);)
     if (bm == 3064 && bn == 64) return launch_kg2<T, 64, 64, CONV>(p, stream);
 #ifndef IMH_EXPERIMENTAL

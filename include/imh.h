@@ -154,7 +154,7 @@ typedef struct imh_gemm_args {
     /* tile variant (0 = heuristic): bm in {64, 128} x bn in {64, 128}: two-stage tiles (gemm.hip); 256 x {128, 256}:
      * 8-wave rings; 3064 x 64 / 3128 x 128: KG2; 4064 / 4128 / 5064: small-tile rings; 5258 x 320, 6128 x 320: the
      * 256 x 320 / 128 x 320 exact tilings; 8256 x 256, 9128 x 320, 9256 x 320: ping-pong kernels (gemm_pp.hip);
-     * 1464 / 2464 x 160, 24128 x 160 / 128, 23256 x 160, 22128 x 160 (two workgroups per CU): wave-specialised kernel
+     * 1464 / 2464 x 160, 24128 x 160 / 128, 23256 x 160 / 128, 22128 x 160 (two workgroups per CU): wave-specialised kernel
      * (producer + consumer waves, gemm_ring.hip); 7128 / 7564 x 320 / 160, 7256 x 160 and the weight-ring forms
      * 7328 / 7428 / 7356 x 160: LDS-halo conv3x3 (conv_halo.hip, stride 1). */
     int32_t bm, bn;

@@ -34,7 +34,9 @@ CONFIGS = collections.OrderedDict([
     ("attn1", dict(attn=1)),
     ("attn3", dict(attn=3)),
     ("attn5", dict(attn=5)),
-    ("attn_whole_items", dict(attn=7)),      # the pipelined kernel without the key-quarter workgroups
+    ("attn_whole_items", dict(attn=7)),
+    ("qkv_256x128", dict(tuning={"2048,3840,1280,0,1": [23256, 128, 1]})),      # the one-launch [Q|K|V] of the L = 1024 layers on 240 tiles
+    ("qkv_256x128_all", dict(tuning={"2048,3840,1280,0,1": [23256, 128, 1], "8192,1920,640,0,1": [23256, 128, 1]})),      # the pipelined kernel without the key-quarter workgroups
     # LayerNorm statistics from stand-alone row-statistics launches instead of the producers' epilogues
     ("ln_rowstats", dict(ln_stats=False)),
     ("gn_off", dict(gn_stats=False)),
