@@ -140,13 +140,31 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         float m_run = NEG_BIG, l_run = 0.f;
         const int ntq = (p.Lk / ATT_KV) >> 2;
+        // staging map of attn_stage_tile with ONE wave doing all four sub-maps: row = 32 i + 8 w + lane / 8; the swizzled chunk depends on
+        // (8 (w & 1) + lane / 8) only, so two per-lane sources each (even / odd 8-row groups) + wave-uniform offsets cover the 16 pieces
+        const unsigned char* kq[2];
+        const unsigned char* vq[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int row = par * 8 + (lane >> 3);
+            const int ch = stage_chunk_x(row, lane);
+            kq[par] = (const unsigned char*)((const T*)p.K + ((size_t)b * p.Lk_pad + row) * p.ldk + h * 64 + ch * 8);
+            vq[par] = (const unsigned char*)((const T*)p.Vt + ((size_t)h * 64 + row) * p.ldvt + (size_t)b * p.Lk_pad + ch * 8);
+        }
+        const size_t kstep = (size_t)ATT_KV * p.ldk * sizeof(T), vstep = (size_t)ATT_KV * sizeof(T);
+        const size_t krow16 = (size_t)16 * p.ldk * sizeof(T), vrow16 = (size_t)16 * p.ldvt * sizeof(T);
         for (int t = 0; t < ntq; ++t) {
             const int tile = wave * ntq + t;
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                attn_stage_tile<T>((const T*)p.K, (const T*)p.Vt, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, my, my + ATT_TILE_BYTES, w, lane);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int g16 = i * 2 + (w >> 1);              // 16-row group of the piece
+                    glds16(kq[w & 1] + tile * kstep + g16 * krow16, my + (i * 32 + w * 8) * 128);
+                    glds16(vq[w & 1] + tile * vstep + g16 * vrow16, my + ATT_TILE_BYTES + (i * 32 + w * 8) * 128);
+                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the Q fragments too, at t = 0)
-            attn_tile<T>(my, my + ATT_TILE_BYTES, qf, lane, tile * ATT_KV, p.Lk, c, o, m_run, l_run);
+            attn_tile<T, false>(my, my + ATT_TILE_BYTES, qf, lane, tile * ATT_KV, p.Lk, c, o, m_run, l_run);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the slot are done before it is staged again
         }
         // merge the four partial (m, l, O) of every query row: waves 1..3 park theirs in their (dead) slots, wave 0 combines in a fixed

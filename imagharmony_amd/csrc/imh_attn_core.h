@@ -241,13 +241,15 @@ __device__ __forceinline__ void attn_core(const AttnParams& p, unsigned char* sm
 // One 64-key tile that is already RESIDENT in LDS (K rows at ks, V^T rows at vs, both landed and visible): S^T = K Q^T,
 // online softmax on raw scores, O^T += V^T P^T -- the body of attn_core's loop without the ring (short key sets: the 77 text
 // + T image tokens of the cross-attention layers are staged once, ahead of the fused kernel's projection).
-template <typename T>
+// (MASK = false: the caller guarantees whole tiles -- no key masking code at all; with a run-time `ragged` hipcc if-converts the mask into
+// 84 compare / select instructions per tile)
+template <typename T, bool MASK = true>
 __device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
                                           const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
                                           float& m_run, float& l_run) {
     typedef typename Vec<T>::v8 v8;
     const int hi = lane >> 5;
-    const bool ragged = kbase + ATT_KV > Lk;
+    const bool ragged = MASK && kbase + ATT_KV > Lk;
     f32x16 st[2];
     {
         v8 kf[2][4];
@@ -366,16 +368,25 @@ __device__ __forceinline__ void attn_core_pipe(const AttnParams& p, unsigned cha
         unsigned char* ks = smem + (tile & (S - 1)) * 2 * ATT_TILE_BYTES;
         attn_stage_tile<T>(Kp, Vp, p.Lk_pad, p.ldk, p.ldvt, b, h, tile, ks, ks + ATT_TILE_BYTES, wave, lane);
     };
-    // the same tile in four single-instruction pieces (q = 2 * round + (0: K, 1: V^T))
+    // the same tile in four single-instruction pieces (q = 2 * round + (0: K, 1: V^T)).  The lane's four source addresses are formed ONCE
+    // (for tile 0); a tile step is a wave-uniform byte offset -- the per-piece address arithmetic (64-bit multiplies by ldk / ldvt, ~12
+    // integer VALU instructions a piece, four of them quarter-rate) otherwise sits in the key loop beside a softmax that is VALU-bound
     const int srow = wave * 8 + (lane >> 3);
+    const unsigned char* ksrc[2];
+    const unsigned char* vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + srow;
+        const int ch = stage_chunk_x(row, lane);
+        ksrc[i] = (const unsigned char*)(Kp + ((size_t)b * p.Lk_pad + row) * p.ldk + h * 64 + ch * 8);
+        vsrc[i] = (const unsigned char*)(Vp + ((size_t)h * 64 + row) * p.ldvt + (size_t)b * p.Lk_pad + ch * 8);
+    }
+    const size_t kstep = (size_t)ATT_KV * p.ldk * sizeof(T), vstep = (size_t)ATT_KV * sizeof(T);
     auto stage_piece = [&](int tile, int q) {
         unsigned char* ks = smem + (tile & (S - 1)) * 2 * ATT_TILE_BYTES;
         const int i = q >> 1;
-        const int row = i * 32 + srow;
-        const int ch = stage_chunk_x(row, lane);
-        const int kbase = tile * ATT_KV;
-        if (q & 1) glds16(Vp + ((size_t)h * 64 + row) * p.ldvt + (size_t)b * p.Lk_pad + kbase + ch * 8, ks + ATT_TILE_BYTES + (i * 32 + wave * 8) * 128);
-        else glds16(Kp + ((size_t)b * p.Lk_pad + kbase + row) * p.ldk + h * 64 + ch * 8, ks + (i * 32 + wave * 8) * 128);
+        if (q & 1) glds16(vsrc[i] + (size_t)tile * vstep, ks + ATT_TILE_BYTES + (i * 32 + wave * 8) * 128);
+        else glds16(ksrc[i] + (size_t)tile * kstep, ks + (i * 32 + wave * 8) * 128);
     };
     f32x16 o[2];
 #pragma unroll
