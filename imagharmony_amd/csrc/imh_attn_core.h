@@ -759,7 +759,7 @@ __device__ __forceinline__ void attn_store(const AttnParams& p, unsigned char* q
             const int ch = lane & 7;
             const v8 o8 = *(const v8*)(qs + tile_off(r2, ch, swz_x(r2)));
             if (q0 + r2 < p.Lq)
-                *(v8*)((T*)p.O + ((size_t)b * p.Lq + q0 + r2) * p.ldo + h * 64 + ch * 8) = o8;
+                st16_wt((v8*)((T*)p.O + ((size_t)b * p.Lq + q0 + r2) * p.ldo + h * 64 + ch * 8), o8);      // (8 lanes = one 128-B line)
         }
     }
 }
