@@ -94,13 +94,16 @@ __device__ __forceinline__ void tail_prefetch(const void* ptr, unsigned bytes, u
 // A 16-B output store at agent scope (`sc1`): WRITE-THROUGH -- the line leaves for memory (the memory-side cache) now instead of staying dirty
 // in this XCD's L2 until the end-of-kernel write-back, which the next kernel waits for (dirty bytes / ~6 TB/s: 0.9 us per 5 MB).  Only for
 // stores that cover whole 32-B sectors with neighbouring lanes (rows written as full lines): scattered 4- / 8- / 16-B pieces measure SLOWER
-// this way, and the non-temporal hint costs the consumer 2-8 us (profiles/NEGATIVE_RESULTS.md, r05_forward_ab_write_through.txt).
+// this way, staging the GEMM epilogues through LDS to make them whole rows gains nothing at the wall, and the non-temporal hint costs the
+// consumer 2-8 us (profiles/r05_forward_ab_write_through.txt).
 template <typename V>
 __device__ __forceinline__ void st16_wt(V* p, const V& t) {
     static_assert(sizeof(V) == 16, "one dwordx4");
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     const u4 d = __builtin_bit_cast(u4, t);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    // (s_nop: a VMEM store of more than 64 bits still reads its data registers for a few cycles after issue, and hipcc's hazard recognizer
+    // does not look inside inline asm -- without it the next VALU write to `d` corrupts the stored line)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(d) : "memory");
 }
 
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
