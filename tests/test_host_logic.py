@@ -413,3 +413,20 @@ def test_derived_weight_caches_follow_in_place_updates():
     sd["to_k.weight"] = sd["to_k.weight"] + 1.0
     attn.load_state_dict(sd)              # load_state_dict copies in place
     assert not torch.equal(_packed_qk(attn, ctx), qk1)
+
+def test_inline_asm_vmem_stores_carry_their_hazard_nop():
+    """hipcc's hazard recognizer does not look inside inline asm: a global_store of more than 64 bits issued from asm still reads its data
+    registers when the next instruction overwrites them (round 5: an LDS-staged epilogue built on such a store returned corrupted lines
+    and looked 1.5 ms per forward faster).  Every inline-asm VMEM store in the kernel sources must be followed by an s_nop in the same
+    asm statement."""
+    import re
+    csrc = os.path.join(ROOT, "imagharmony_amd", "csrc")
+    found = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r'asm volatile\("(global_store_dwordx[24][^"]*)"', src):
+            found += 1
+            assert "s_nop" in m.group(1), f"{f}: inline-asm store without its hazard nop: {m.group(1)[:80]}"
+    assert found >= 1
