@@ -362,33 +362,67 @@ class ClockSampler:
                 "note": "rocm-smi sampled from the host during the timed steps; `roofline.peak` stays the 2.4 GHz figure"}
 
 
-def pns_two_stage(eng, pipe, device, lat_shape, N=8, preview_steps=10, final_steps=30):
+def pns_two_stage(eng, pipe, unet, cond, device, dtype, lat_shape, res, N=8, preview_steps=10, final_steps=30, stack=4):
     """the two-stage schedule of assets/1.png / README.md:27 on ONE rank, end to end: N candidate seeds x a `preview_steps` denoise,
     the judge, then the judged-best noise x the full `final_steps` denoise -- so that the serial tail of the scheme is a number
     (at W ranks with N = W the tail runs on the owner rank while the others idle: (N * p + f) / (p + f) is the ceiling of the
-    speed-up, 2.75x for 8 x 10 + 30).  Uses the latent-statistic judge (off the measured path's critical work, like bench `value`)."""
+    speed-up, 2.75x for 8 x 10 + 30).  Uses the latent-statistic judge (off the measured path's critical work, like bench `value`).
+    The previews run `stack` candidates per UNet forward (UNet batch 2 * stack with CFG) -- the mode IPAdapterXL.generate_pns picks by
+    itself when a rank holds more than one seed (round 6) -- and, for comparison, one at a time (rounds 3-5); both modes must name
+    the same winner."""
     from imagharmony_amd import pns
-    prev = eng.fork()
-    prev.set_schedule(pipe.scheduler, preview_steps)
+    pe, ne, po, no = cond
+    S = max(1, min(int(stack), N))
+    prev1 = eng.fork()
+    prev1.set_schedule(pipe.scheduler, preview_steps)
+    prevS = eng.__class__(unet, device, dtype, True)
+    prevS.set_conditioning(pe.repeat(S, 1, 1), ne.repeat(S, 1, 1), po.repeat(S, 1), no.repeat(S, 1), res, res, guidance_scale=5.0)
+    prevS.set_schedule(pipe.scheduler, preview_steps)
     noises = [pns.seed_latents(5000 + j, lat_shape).to(device) for j in range(N)]
-    prev.denoise(noises[0]); eng.denoise(noises[0])            # plans recorded / captured outside the timed region
+    groups = [torch.cat(noises[j:j + S], 0) for j in range(0, N - N % S, S)]
+    tail = noises[N - N % S:]                                  # N not a multiple of the stack: the rest one at a time
+    prev1.denoise(noises[0]); prevS.denoise(groups[0]); eng.denoise(noises[0])      # plans recorded / captured outside the timed region
     torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    scores = [pns.default_scorer(prev.denoise(z)) for z in noises]
-    best = int(torch.argmax(torch.cat(scores)))            # (reads the scores back: the previews are done)
-    torch.cuda.synchronize(device)
-    t1 = time.perf_counter()
-    out = eng.denoise(noises[best])
-    torch.cuda.synchronize(device)
-    t2 = time.perf_counter()
+
+    def run(previews):
+        t0 = time.perf_counter()
+        scores = previews()
+        best = int(torch.argmax(torch.cat(scores)))            # (reads the scores back: the previews are done)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        out = eng.denoise(noises[best])
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        return best, t1 - t0, t2 - t1, out, torch.cat(scores)
+
+    b1, p1, f1, _, sc1 = run(lambda: [pns.default_scorer(prev1.denoise(z)) for z in noises])
+    bS, pS, fS, out, scS = run(lambda: [pns.default_scorer(prevS.denoise(g)) for g in groups] +
+                                       [pns.default_scorer(prev1.denoise(z)) for z in tail])
     fw = N * preview_steps + final_steps
-    return {"N": N, "preview_steps": preview_steps, "final_steps": final_steps, "seconds_per_pns_run": t2 - t0,
-            "final_images_per_sec": 1.0 / (t2 - t0), "preview_seconds": t1 - t0, "final_seconds": t2 - t1, "unet_forwards": fw,
-            "ms_per_unet_forward": (t2 - t0) / fw * 1e3, "serial_tail_share_at_8_ranks": (t2 - t1) / ((t1 - t0) / N + (t2 - t1)),
-            "ceiling_speedup_8_ranks": (t2 - t0) / ((t1 - t0) / N + (t2 - t1)), "outputs_finite": bool(torch.isfinite(out).all().item()),
-            "note": "one rank runs all N previews back to back, then the final denoise; at 8 ranks the previews shard 8 ways and the "
-                    "final denoise stays on the owner rank (pns.run_pns) unless its CFG halves are split over two ranks "
-                    "(DenoiseEngine.denoise_cfg_split through pns.run_pns(final_split_fn=...): measured no faster, DESIGN.md 7)"}
+    tot = pS + fS
+    return {"N": N, "preview_steps": preview_steps, "final_steps": final_steps, "previews_per_forward": S,
+            "seconds_per_pns_run": tot, "final_images_per_sec": 1.0 / tot, "preview_seconds": pS, "final_seconds": fS,
+            "best_seed_index": bS, "unet_forwards_equivalent": fw, "ms_per_unet_forward_equivalent": tot / fw * 1e3,
+            "one_at_a_time": {"seconds_per_pns_run": p1 + f1, "preview_seconds": p1, "final_seconds": f1, "best_seed_index": b1},
+            "same_winner_in_both_modes": bool(b1 == bS),
+            "max_abs_score_difference_between_modes": float((sc1 - scS).abs().max().item()),
+            "serial_tail_share_at_8_ranks": f1 / (p1 / N + f1),
+            "ceiling_speedup_8_ranks": (p1 + f1) / (p1 / N + f1), "outputs_finite": bool(torch.isfinite(out).all().item()),
+            "note": "one rank runs all N previews, then the final denoise of the judged-best noise.  `seconds_per_pns_run` = previews stacked "
+                    f"{S} per UNet forward (pns.run_pns(batch={S}), the default of generate_pns when a rank holds several seeds); `one_at_a_time` = "
+                    "the rounds 3-5 mode.  At 8 ranks the previews shard 8 ways (one seed per rank, batch 1) and the final denoise stays on the "
+                    "owner rank (pns.run_pns) unless its CFG halves are split over two ranks (DenoiseEngine.denoise_cfg_split through "
+                    "pns.run_pns(final_split_fn=...): measured no faster, DESIGN.md 7); the ceiling / tail share are for that one-seed-per-rank case"}
+
+
+def _device_identity(device):
+    """something that differs between two physical GPUs of one node and is equal for two ranks on the same one"""
+    pr = torch.cuda.get_device_properties(device)
+    ident = getattr(pr, "uuid", None)
+    if ident is not None:
+        return str(ident)
+    pci = tuple(getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return str(pci) if any(v is not None for v in pci) else f"index {device.index}"
 
 
 def _self_launch(n, script=None, argv=None):
@@ -418,12 +452,24 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.backend, rank=rank, world_size=world)
-    if a.gpus != world and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    if os.environ.get("IMH_BENCH_SHARE_GPU") == "1":      # testing aid: every rank on GPU 0 (needs --backend gloo)
+    share_gpu = os.environ.get("IMH_BENCH_SHARE_GPU") == "1"      # testing aid: every rank on GPU 0 (needs --backend gloo)
+    if share_gpu:
         local = 0
+    # a multi-GPU line must be what it says it is: the launcher's world, the backend's world and --gpus agree, and no two ranks
+    # share a device (a mis-launched "8-GPU" run on fewer devices would otherwise report a plausible-looking number)
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N starts them itself)")
+    if world > 1 and dist.get_world_size() != a.gpus:
+        raise SystemExit(f"bench.py: the {a.backend} backend reports world size {dist.get_world_size()}, --gpus says {a.gpus}")
+    if world > 1 and not share_gpu and local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK={local} but only {torch.cuda.device_count()} devices are visible")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
+    if world > 1:
+        ids = [None] * world
+        dist.all_gather_object(ids, _device_identity(device))
+        if not share_gpu and len(set(ids)) != world:
+            raise SystemExit(f"bench.py: ranks share a device: {ids}")
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
 
     from imagharmony_amd import lib as L
@@ -433,7 +479,22 @@ def main():
     L.load()
 
     unet = build_unet(device, dtype, a.ip_tokens)
-    pns.broadcast_module_(unet, src=0)                       # one-time weight broadcast over xGMI (RCCL)
+    collectives = None
+    if world > 1:
+        # the one-time weight broadcast over xGMI (RCCL), timed: first call (communicator set-up + transfer), then once more warm --
+        # outside `value`, reported under config.distributed.collectives
+        w_bytes = sum(t.numel() * t.element_size() for t in list(unet.parameters()) + list(unet.buffers()))
+        bt = []
+        for _ in range(2):
+            torch.cuda.synchronize(device); dist.barrier(); torch.cuda.synchronize(device)
+            tb = time.perf_counter()
+            n_coll = pns.broadcast_module_(unet, src=0)
+            torch.cuda.synchronize(device); dist.barrier()
+            bt.append(time.perf_counter() - tb)
+        collectives = {"weight_broadcast": {"bytes": w_bytes, "GB": w_bytes / 1e9, "collectives": n_coll, "first_call_s": bt[0], "warm_s": bt[1],
+                                            "warm_GB_per_s": w_bytes / 1e9 / bt[1],
+                                            "note": "pns.broadcast_module_: the UNet replica of rank 0 to every rank as flat 512-MB buckets "
+                                                    "(dist.broadcast, backend as reported); once per process, never in `value`"}}
     pe, ne, po, no = synthetic_conditioning(a.ip_tokens)
     cond = [t.to(device) for t in (pe, ne, po, no)]
     pns.broadcast_tensors_(cond, src=0)
@@ -519,6 +580,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         allscores = [torch.empty_like(torch.cat(scores)) for _ in range(world)]
         dist.all_gather(allscores, torch.cat(scores))        # final gather of the candidate scores
+        torch.cuda.synchronize(device)
+        tg = time.perf_counter()
+        dist.all_gather(allscores, torch.cat(scores))        # ... once more, warm and timed (outside `value`)
+        torch.cuda.synchronize(device)
+        collectives["score_all_gather"] = {"floats_per_rank": int(torch.cat(scores).numel()), "warm_s": time.perf_counter() - tg,
+                                           "note": "the only collective after a PNS run's denoises besides the winner broadcast (pns.run_pns)"}
     dt = float(tmax.item())
     finite = bool(torch.isfinite(out).all().item())
 
@@ -574,6 +641,7 @@ def main():
                        "distributed": {"world_size_reported_by_backend": dist.get_world_size() if world > 1 else 1,
                                        "backend": dist.get_backend() if world > 1 else None,
                                        "per_rank_ms_per_step": per_rank,
+                                       "collectives": collectives,
                                        "devices_visible": torch.cuda.device_count()},
                        "conditioning_prepare_ms": {"first_call": cond_ms[0], "later_calls": cond_ms[1:],
                                                    "note": "DenoiseEngine.set_conditioning: K / V caches of the 70 cross-attention layers (140 small GEMMs "
@@ -687,7 +755,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 res["box_calibration"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                res["pns_two_stage"] = pns_two_stage(eng, pipe, device, lat_shape)
+                res["pns_two_stage"] = pns_two_stage(eng, pipe, unet, (pe, ne, po, no), device, dtype, lat_shape, a.res, stack=a.stacked)
             except Exception as e:      # noqa: BLE001
                 res["pns_two_stage"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
@@ -721,6 +789,12 @@ def main():
                 res["resampler"] = resampler_extra(device, dtype)
             except Exception as e:      # noqa: BLE001
                 res["resampler"] = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            # the CPU baseline is a property of the box, timed on rank 0 of the N = 1 run only (it would steal host cores from N ranks'
+            # launch threads here); the field stays present so that every line carries it
+            res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
+                                   "sample": "see the N = 1 line of the same round (python bench.py --gpus 1): the fp32 CPU oracle, "
+                                             "1 warm-up + 2 timed 1024^2 CFG-2 UNet forwards x 30 steps"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_res, a.ip_tokens, a.denoise_steps)

@@ -241,7 +241,7 @@ class IPAdapterXL(IPAdapter):
 
     @torch.no_grad()
     def generate_pns(self, seeds, pil_image=None, prompt=None, negative_prompt=None, extra_text=None, scale=1.0,
-                     preview_steps=10, num_inference_steps=30, guidance_scale=5.0, scorer=None, batch=1,
+                     preview_steps=10, num_inference_steps=30, guidance_scale=5.0, scorer=None, batch=None,
                      clip_image_embeds=None, prompt_embeds=None, extra_prompt_embeds=None, height=None, width=None,
                      output_type="pil", **schedule_kw):
         """Preference-guided noise selection (README.md:27, assets/1.png) around ``generate``: every candidate seed gets
@@ -249,6 +249,9 @@ class IPAdapterXL(IPAdapter):
         denoise.  Candidates are sharded over the ranks of an initialised torch.distributed group (one process per
         GPU; no per-step collective).  ``scorer`` (latents [S,4,h,w] -> [S]) defaults to the CLIP-space judge when a
         VAE and a CLIP vision model are attached, else to the latent statistic of ``pns.default_scorer``.
+        ``batch`` = preview candidates stacked per UNet forward on a rank; None (default) = as many as the rank holds, up
+        to 4 (BASELINE.json configs[4] runs 4 per GPU): a stacked forward costs 1.27x less per candidate than one at a
+        time on MI355X (bench.py ``stacked_candidates`` / ``pns_two_stage``); the final denoise is batch 1 either way.
         Returns dict(images, best_seed, scores, latents)."""
         from . import pns
         self.set_scale(scale)
@@ -270,6 +273,10 @@ class IPAdapterXL(IPAdapter):
         ne = torch.cat([ne.to(ipe.device, self.dtype), uipe], dim=1)
         height = height or pipe.default_sample_size * pipe.vae_scale_factor
         width = width or pipe.default_sample_size * pipe.vae_scale_factor
+        if batch is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            batch = min(4, (len(list(seeds)) + world - 1) // world)
         S = max(1, int(batch))
         eng = pipe.engine
         rep = lambda t, n: t.repeat(*([n] + [1] * (t.ndim - 1)))

@@ -484,8 +484,11 @@ def test_generate_pns_two_stage_with_clip_judge():
     kw = dict(pil_image=img, prompt_embeds=embeds, extra_prompt_embeds=det_randn((1, 77, cd), 6), preview_steps=10,
               num_inference_steps=30, guidance_scale=5.0, height=256, width=256)
     seeds = [3, 9, 27, 81]
-    r1 = ip.generate_pns(seeds, **kw)
+    r1 = ip.generate_pns(seeds, batch=1, **kw)               # one candidate per forward (the rounds 3-5 default)
     r2 = ip.generate_pns(seeds, batch=2, **kw)               # two candidates stacked per forward: same winner
+    r4 = ip.generate_pns(seeds, **kw)                        # the default: all four of this rank's seeds in one UNet batch of 8
+    assert r4["best_seed"] == r1["best_seed"] or max(r1["scores"].flatten().tolist()) - r1["scores"].flatten().tolist()[seeds.index(r4["best_seed"])] < 5e-2
+    assert (r1["scores"] - r4["scores"]).abs().max() < 5e-2
     assert isinstance(r1["images"][0], Image.Image) and r1["images"][0].size == (256, 256)
     assert r1["best_seed"] in seeds and r2["best_seed"] in seeds
     # same winner -- unless two candidates tie within the batched-vs-batch-1 rounding band allowed below (random CLIP
