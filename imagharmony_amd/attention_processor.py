@@ -180,7 +180,7 @@ class AttnProcessor2_0(nn.Module):
         else:
             # [Q|K] = x [Wq;Wk]^T  [M, 2C]  and  V^T = Wv x^T  [C, M]  share x: ONE launch -- with handed-over LayerNorm statistics
             # the wave-specialised pair (variant 24128: 128 x 160 + 128 x 128 tiles), else the two-stage 128-row tiles
-            ws = ln is not None and ln_stats is not None and DUAL_WS and (B * L_) % 128 == 0 and C_ % 160 == 0
+            ws = ln is not None and ln_stats is not None and DUAL_WS and L.experimental() and (B * L_) % 128 == 0 and C_ % 160 == 0      # the wave-specialised two-problem launch is an -DIMH_EXPERIMENTAL kernel: fall back to (128, 64) on the default library
             qk, vt = ctx.gemm_dual(g1, g2, cfg=(24128, 160) if ws else (128, 64), descr="self.to_qk+v^T")
         ao = ctx.new(B * L_, C_)
         ctx.attention(qk[:, :C_], qk[:, C_:], vt, ao, B, H, L_, lk or L_, L_, 2 * C_, 2 * C_, B * L_, C_,

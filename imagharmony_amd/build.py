@@ -57,6 +57,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -54,7 +54,8 @@ __device__ __forceinline__ void gn_group_stats(const GnTabSrc& g, const int b, c
         const f2* base = (const f2*)pp + (size_t)b * nblk * nsub + j0;
         const int total = nblk * nj;
         const double inv_const = npart > 0 ? 1.0 / (double)npart : 0.0;
-        // sixteen partials in flight per lane (one batch covers the 256 partials of any SDXL group) (all loads of a batch issued before the first add; the adds keep the ascending order of e,
+        // UB = 8 partials in flight per lane, GN_GL = 16 lanes per group: one batch covers 128 partials, so the SDXL groups with 256 partials take two dependent
+        // L2 round trips (UB = 16 would take one, at 16 more live registers in the 128-register conv forms) (all loads of a batch issued before the first add; the adds keep the ascending order of e,
         // so the sums are those of the plain loop -- which cost one L2 round trip PER partial: 8-10 us in a conv's prologue)
         constexpr int UB = 8;
         for (int e0 = l; e0 < total; e0 += GN_GL * UB) {

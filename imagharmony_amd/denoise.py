@@ -6,6 +6,7 @@ One denoise step = [UNet forward on the CFG-duplicated latent] + [CFG combine + 
 scale and the per-step IP-scale gate (control_guidance_start/end, custom_pipelines.py:326-329) are
 device tables indexed by a device-resident step counter.
 """
+import hashlib
 import os
 
 import torch
@@ -36,6 +37,7 @@ class DenoiseEngine:
         self.xcd_cells = None
         self._is_fork = False
         self._plans = {}         # recorded plans by schedule key (two-stage PNS alternates a preview and a final schedule per image)
+        self.max_cached_plans = int(os.environ.get("IMH_MAX_CACHED_PLANS", "3"))      # each pins ~2 GB of activation buffers at 1024^2
         self._sched_key = None
 
     # -- conditioning (once per image / per PNS run; shared by every candidate seed) --
@@ -90,12 +92,20 @@ class DenoiseEngine:
         st, dev = self.st, self.device
         from .attention_processor import IPAttnProcessor2_0
         base = next((p.scale for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor2_0)), 1.0)
-        key = (type(scheduler).__name__, int(getattr(scheduler, "num_train_timesteps", 1000)), int(num_inference_steps), float(control_guidance_start), float(control_guidance_end), denoising_end, float(base))
+        # the key carries a fingerprint of the tables themselves (timesteps, coefficients, input scale, init sigma): a scheduler instance
+        # configured differently (betas, spacing, prediction type) under the same class name must not reuse another schedule's plan
+        scheduler.set_timesteps(num_inference_steps)
+        tab = scheduler.tables()
+        fp = hashlib.sha1()
+        for k in ("timesteps", "coef", "in_scale"):
+            v = tab.get(k)
+            fp.update(b"-" if v is None else v.detach().to("cpu", torch.float64).contiguous().numpy().tobytes())
+        fp.update(repr(float(tab["init_noise_sigma"])).encode())
+        key = (type(scheduler).__name__, int(getattr(scheduler, "num_train_timesteps", 1000)), int(num_inference_steps), float(control_guidance_start), float(control_guidance_end), denoising_end, float(base), fp.hexdigest())
         hit = self._plans.get(key)
         if hit is not None:
             # a schedule this engine has run under this conditioning: its tables, time-embedding rows and recorded plan are still there
             # (the plan's launches point at them), so a preview / final alternation re-records nothing
-            scheduler.set_timesteps(num_inference_steps)
             for k in ("t_table", "coef_tab", "in_scale_tab", "ip_scale_tab", "temb_table"):
                 setattr(st, k, hit["st"][k])
             self.steps, self.init_noise_sigma = hit["steps"], hit["init_noise_sigma"]
@@ -103,8 +113,6 @@ class DenoiseEngine:
             self.plan_tail, self.np_full = hit.get("plan_tail"), hit.get("np_full")
             self._sched_key = key
             return
-        scheduler.set_timesteps(num_inference_steps)
-        tab = scheduler.tables()
         n = num_inference_steps
         if denoising_end is not None and isinstance(denoising_end, float) and 0 < denoising_end < 1:
             # custom_pipelines.py:303-311: stop once t falls below the cut-off; the gating window below then counts
@@ -203,7 +211,7 @@ class DenoiseEngine:
             st={k: getattr(st, k, None) for k in ("t_table", "coef_tab", "in_scale_tab", "ip_scale_tab", "temb_table")},
             steps=self.steps, init_noise_sigma=self.init_noise_sigma, plan=self.plan, noise_pred=self.noise_pred,
             temb_ctx=self._temb_ctx, plan_tail=getattr(self, "plan_tail", None), np_full=getattr(self, "np_full", None))
-        while len(self._plans) > 3:              # (each plan keeps ~2 GB of activation buffers alive at 1024^2)
+        while len(self._plans) > self.max_cached_plans:              # (each plan keeps ~2 GB of activation buffers alive at 1024^2)
             self._plans.pop(next(iter(self._plans)))
 
     def _pick_xcd_cells(self):

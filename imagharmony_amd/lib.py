@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("IMH_LIB_PATH") or os.path.join(_HERE, "libimh_hip.so")   # override: experimental builds (tools/)
+# IMH_LIB_PATH overrides; IMH_EXPERIMENTAL=1 (the switch build.py compiles the experimental library under) selects that library by itself,
+# so that the one variable builds AND loads the same file
+_EXP_PATH = os.path.join(_HERE, "..", "tools", "tmp_libs", "libimh_hip_experimental.so")
+LIB_PATH = os.environ.get("IMH_LIB_PATH") or (_EXP_PATH if os.environ.get("IMH_EXPERIMENTAL") == "1" else os.path.join(_HERE, "libimh_hip.so"))
 
 ABI_VERSION = 8
 IMH_DT_BF16, IMH_DT_F16 = 0, 1

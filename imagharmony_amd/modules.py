@@ -7,6 +7,7 @@ classes; ``forward`` issues GEMM / LayerNorm / small-attention kernels through t
 torch.cat / views are data plumbing only.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,7 +26,14 @@ class Graphed:
     """A conditioning module (Resampler, ImageProjModel, HarmonyAttention: ~10-45 small launches, once or twice per image) as a hipGraph:
     the first call per (input shapes, dtypes, parameter storage) runs the module once on a side stream and captures a second run; later
     calls copy the inputs into the captured buffers and replay -- 0.8 ms instead of an eager pass whose host time wanders between 0.8 and
-    7 ms (BENCH_r04 `resampler`).  Outputs are clones (the captured buffers are overwritten by the next call)."""
+    7 ms (BENCH_r04 `resampler`).  Outputs are clones (the captured buffers are overwritten by the next call).
+
+    What a replay re-reads and what it freezes: parameters and buffers are read by the captured kernels at replay time through the
+    pointers they had at capture (in-place updates are seen; the key below covers their storage pointers AND versions, so a re-assigned or
+    in-place-modified tensor re-captures).  Plain Python attributes, and anything a module DERIVES from its weights and caches (folded /
+    packed weights), are baked into the graph: the three wrapped modules derive nothing -- a module that does must not be wrapped (or must
+    bump a parameter's version when the cache changes).  The capture uses the default (global) capture mode and therefore assumes that no
+    other host thread allocates on this device meanwhile.  ``IMH_GRAPHED=0`` in the environment turns the wrapper into a plain eager call."""
 
     def __init__(self, module):
         self.module = module
@@ -36,9 +44,10 @@ class Graphed:
 
     @torch.no_grad()
     def __call__(self, *xs):
-        if not xs or any((not torch.is_tensor(x)) or x.device.type != "cuda" for x in xs):
+        if not xs or any((not torch.is_tensor(x)) or x.device.type != "cuda" for x in xs) or os.environ.get("IMH_GRAPHED", "1") == "0":
             return self.module(*xs)
-        key = tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(p.data_ptr() for p in self.module.parameters())
+        key = tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + \
+            tuple((t.data_ptr(), t._version) for t in list(self.module.parameters()) + list(self.module.buffers()))
         ent = self._cache.get(key)
         if ent is None:
             dev = xs[0].device
