@@ -55,16 +55,6 @@ constexpr int CH_HW = CH_PW + 2;                          // halo row length (18
 #else
 #define CH_TICK(i) do {} while (0)
 #endif
-__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
-#define IMH_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {       // wave-uniform; the immediate must be a literal
-        IMH_VMC(0) IMH_VMC(1) IMH_VMC(2) IMH_VMC(3) IMH_VMC(4) IMH_VMC(5) IMH_VMC(6) IMH_VMC(7) IMH_VMC(8) IMH_VMC(9) IMH_VMC(10) IMH_VMC(11)
-        IMH_VMC(12) IMH_VMC(13) IMH_VMC(14) IMH_VMC(15) IMH_VMC(16) IMH_VMC(17) IMH_VMC(18) IMH_VMC(19) IMH_VMC(20) IMH_VMC(21) IMH_VMC(22)
-        IMH_VMC(23) IMH_VMC(24) IMH_VMC(25) IMH_VMC(26) IMH_VMC(27) IMH_VMC(28) IMH_VMC(29) IMH_VMC(30)
-        default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
-    }
-#undef IMH_VMC
-}
 
 // HWV = 0: eight waves do everything (rounds 2-3).  HWV = 4 (round 4): four extra HALO waves own the input side -- they issue the
 // halo LDS-DMA of the next chunk and normalise it in place (GroupNorm + SiLU, p.gn_tab), two pieces per tap, while the eight MFMA

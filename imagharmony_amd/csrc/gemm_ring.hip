@@ -830,6 +830,49 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid,
             return;
         }
     }
+    if constexpr (LN == 0 && NC + NP > 8) {
+        // Round 6: the twelve-wave forms (256 x 160: the UNet-batch-8 to_out / ff.out / proj_out) take the same shortcut with the residual rows
+        // kept PACKED (FM x 10 registers beside the 80 accumulators; the fragment registers are dead by now): ALL of the lane's residual
+        // rows and the bias are requested before the first store.  Through the generic epilogue below each row's residual load queued behind
+        // the previous row's stores -- 9.6 us from the end of the K loop to the last store of an 8192 x 1280 x 1280 launch against 5.0 us
+        // without a residual (profiles/r06_ws_timeline.txt)
+        if (p.flags == 0 && !p.rowadd && p.residual && p.bias && p.splits == 1 && epilogue_fast<T, 4 * FN>(p, nb)) {
+            constexpr int NV = 4 * FN;
+            RawRow<T, NV> bs_r, rr_r[FM];
+            bool ok[FM];
+            ldraw<T, NV>((const T*)p.bias + nb, bs_r);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                ok[i] = m < p.M;
+                ldraw<T, NV>((const T*)p.residual + (size_t)min(m, p.M - 1) * p.ldr + nb, rr_r[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if (!ok[i]) continue;
+                const int m = m0 + wm * TM + i * 16 + (lane & 15);
+                float v[NV], bs[NV], rr[NV];
+                unraw<T, NV>(bs_r, bs);
+                unraw<T, NV>(rr_r[i], rr);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bs[j * 4 + r] + rr[j * 4 + r];
+                stv<T, NV>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+                if (p.ln_stats_out) emit_row_stats<T, NV>(p.ln_stats_out, p.ln_slots_out, m, nb, v, lane);
+                if constexpr (NV % 10 == 0) {
+                    if (p.gn_out) gn_accumulate<T, NV>(v, gna, i == 0);
+                }
+            }
+            if constexpr (NV % 10 == 0) {
+                if (p.gn_out) {
+                    const int mw = m0 + wm * TM;
+                    if (mw < p.M) gn_emit<NV>(p.gn_out, p.gn_nblk, p.N / 10, mw / p.gn_hw, (mw % p.gn_hw) / TM, nb, gna, FM, lane);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
@@ -868,6 +911,13 @@ template <typename T, int BM, int BN, int CM, int CN, int S, int NP, bool CONV, 
 __global__ __launch_bounds__(64 * (CM * CN + NP), OCC == 1 ? 1 : OCC * (CM * CN + NP) / 4) void gemm_ws_kernel(const GemmParams p) {      // (HIP: the second value is waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gemm_ws_body<T, BM, BN, CM, CN, S, NP, CONV, LN>(p, blockIdx.x, gridDim.x, smem);
+#if WS_TIMING
+    // per-workgroup time line: consumer wave 0's stores have left the wave -> exit stamp (tools/ws_timeline_probe.py)
+    if (threadIdx.x == 0 && p.pf_ptr && p.pf_bytes == 0xfeed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ((unsigned long long*)p.pf_ptr)[8 + (size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 #ifdef IMH_EXPERIMENTAL

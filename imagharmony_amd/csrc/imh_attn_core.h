@@ -53,6 +53,11 @@ __device__ __forceinline__ float xhalf_max(float x) {
 #endif
 
 
+template <typename T, bool MASK, int NKT>
+__device__ __forceinline__ void attn_tile_n(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
+                                            const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
+                                            float& m_run, float& l_run);
+
 // The key loop: NPASS key sets (text [, image-prompt]) against the Q^T fragments `qf` of this wave's 32 queries;
 // returns fin = sum over passes of weight * softmax(QK^T) V, transposed (lane owns one query, att_o_dim head dims).
 // smem = the ATT_STAGES * 16 KB ring; every wave of the workgroup must call this (workgroup barriers inside), and no
@@ -132,6 +137,17 @@ __device__ __forceinline__ void attn_core(const AttnParams& p, unsigned char* sm
             const unsigned char* vs = ks + ATT_TILE_BYTES;
             const int kbase = t * ATT_KV;
             const bool ragged = kbase + ATT_KV > Lk;   // only the last tile of a ragged key set needs masking
+#if !ATT_ABL && !ATT_TIMING
+            // Round 6: a tile whose second 32-key sub-tile is all padding (the 13 keys of the text set's second tile, an image-prompt set
+            // of <= 32 tokens: three of the four tiles a fused cross-attention call touches) takes the half-width body -- bit-identical
+            // (the skipped scores exponentiate to exactly 0), 8 of 16 MFMAs and 16 of 32 v_exp_f32 fewer
+            if (kbase + 32 >= Lk) {                     // wave-uniform
+                attn_tile_n<T, true, 1>(ks, vs, qf, lane, kbase, Lk, c, o, m_run, l_run);
+                asm volatile("" ::: "memory");
+                if (++cur == ATT_STAGES) cur = 0;
+                continue;
+            }
+#endif
 
             // ---- S^T = K Q^T (both 32-key sub-tiles always: padded keys are zero rows, masked below).
             //      MFMA and VALU time add up on a SIMD (tools/attn_ablate.py), so LDS latency is what can be hidden:
@@ -243,23 +259,26 @@ __device__ __forceinline__ void attn_core(const AttnParams& p, unsigned char* sm
 // + T image tokens of the cross-attention layers are staged once, ahead of the fused kernel's projection).
 // (MASK = false: the caller guarantees whole tiles -- no key masking code at all; with a run-time `ragged` hipcc if-converts the mask into
 // 84 compare / select instructions per tile)
-template <typename T, bool MASK = true>
-__device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
-                                          const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
-                                          float& m_run, float& l_run) {
+// NKT = 32-key sub-tiles computed (2 = the whole tile; 1 = only the first: every key of the second is padding -- the 13 valid keys of the
+// text set's second tile, an image-prompt set of <= 32 tokens -- whose scores would be masked to NEG_BIG, exponentiate to exactly 0 and add
+// exactly 0 to the row sums and to O: skipping them is bit-identical and saves 8 of the tile's 16 MFMAs and 16 of its 32 v_exp_f32).
+template <typename T, bool MASK, int NKT>
+__device__ __forceinline__ void attn_tile_n(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
+                                            const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
+                                            float& m_run, float& l_run) {
     typedef typename Vec<T>::v8 v8;
     const int hi = lane >> 5;
-    const bool ragged = MASK && kbase + ATT_KV > Lk;
-    f32x16 st[2];
+    const bool ragged = MASK && kbase + 32 * NKT > Lk;
+    f32x16 st[NKT];
     {
-        v8 kf[2][4];
+        v8 kf[NKT][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int sd = 0; sd < 4; ++sd) kf[kt][sd] = *(const v8*)(ks + att_k_off(lane, kt, sd));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
@@ -267,9 +286,9 @@ __device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigne
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    v8 vf[2][2][2];
+    v8 vf[NKT][2][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -277,24 +296,31 @@ __device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigne
     __builtin_amdgcn_sched_barrier(0);
     if (ragged) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kbase + kt * 32 + st_key(r, hi) >= Lk) st[kt][r] = NEG_BIG;
     }
-    float mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
-    mx = fmaxf(mx, st[0][2]);
+    float mx;
+    if constexpr (NKT == 2) {
+        mx = max3f(mfma_first_max(st[0][0], st[1][0]), st[0][1], st[1][1]);
+        mx = fmaxf(mx, st[0][2]);
 #pragma unroll
-    for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
-    mx = fmaxf(mx, st[1][15]);
+        for (int r = 2; r < 15; ++r) mx = max3f(mx, st[1][r], st[0][r + 1]);
+        mx = fmaxf(mx, st[1][15]);
+    } else {
+        mx = max3f(mfma_first_max(st[0][0], st[0][1]), st[0][2], st[0][3]);
+#pragma unroll
+        for (int r = 4; r < 16; r += 2) mx = max3f(mx, st[0][r], st[0][r + 1]);
+    }
     mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const f32x2 c2 = {c, c};
     const f32x2 nmc2 = {-m_new * c, -m_new * c};
     f32x2 ps2 = {0.f, 0.f};
-    v8 pf[2][2];
+    v8 pf[NKT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const f32x2 s2 = {st[kt][r], st[kt][r + 1]};
@@ -316,11 +342,19 @@ __device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigne
     l_run += ps2[0] + ps2[1];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s][dt], pf[kt][s], o[dt]);
+}
+
+template <typename T, bool MASK = true>
+__device__ __forceinline__ void attn_tile(const unsigned char* ks, const unsigned char* vs, const typename Vec<T>::v8 (&qf)[4],
+                                          const int lane, const int kbase, const int Lk, const float c, f32x16 (&o)[2],
+                                          float& m_run, float& l_run) {
+    if (MASK && kbase + 32 >= Lk) attn_tile_n<T, MASK, 1>(ks, vs, qf, lane, kbase, Lk, c, o, m_run, l_run);      // (wave-uniform)
+    else attn_tile_n<T, MASK, 2>(ks, vs, qf, lane, kbase, Lk, c, o, m_run, l_run);
 }
 
 // LDS-DMA of one 64-key K / V^T tile pair by the four waves of a head group (wave = 0..3 inside the group): the staging map

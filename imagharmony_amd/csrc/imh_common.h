@@ -73,6 +73,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal): counted waits of rings whose in-flight depth varies at the ends
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
+#define IMH_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {       // wave-uniform; the immediate must be a literal
+        IMH_VMC(0) IMH_VMC(1) IMH_VMC(2) IMH_VMC(3) IMH_VMC(4) IMH_VMC(5) IMH_VMC(6) IMH_VMC(7) IMH_VMC(8) IMH_VMC(9) IMH_VMC(10) IMH_VMC(11)
+        IMH_VMC(12) IMH_VMC(13) IMH_VMC(14) IMH_VMC(15) IMH_VMC(16) IMH_VMC(17) IMH_VMC(18) IMH_VMC(19) IMH_VMC(20) IMH_VMC(21) IMH_VMC(22)
+        IMH_VMC(23) IMH_VMC(24) IMH_VMC(25) IMH_VMC(26) IMH_VMC(27) IMH_VMC(28) IMH_VMC(29) IMH_VMC(30)
+        default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    }
+#undef IMH_VMC
+}
+
 // a 256-B page of zeros: out-of-range tile rows / conv padding taps fetch from here, so
 // the main loops carry no bounds branches
 static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];   // one copy per translation unit

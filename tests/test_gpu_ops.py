@@ -383,6 +383,41 @@ def _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_st
                         ln=lnq, **kw)
     # the reference rounds q once (bf16 / fp16) exactly like the kernel's hand-over; k = 8 ulps of the output scale
     assert_close(out.view(B, Lq, C_), ref, dtype, f"fused cross attention B={B} H={H} Lq={Lq} nt={nt} nip={nip} ln={ln}", k=8.0)
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,nt,nip,ln", [(1, 5, 128, 77, 4, 2), (2, 10, 256, 77, 16, 0), (1, 5, 256, 130, 0, 1), (3, 5, 128, 64, 70, 3),
+                                               (8, 20, 1024, 77, 16, 2), (8, 20, 1024, 77, 32, 2), (2, 10, 4096, 77, 0, 0)])
+def test_fused_cross_attention_wide_form(L, dtype, B, H, Lq, nt, nip, ln):
+    """Round 6: the shape-selected WIDE form of csrc/xattn.hip (one workgroup = batch x 128 queries x FIVE heads, producer waves own
+    the LDS-DMA rings and stream the K / V^T tiles of the key phase; imh_debug_set(3, 10)) -- (a) against the fp32 torch reference of
+    ip_adapter/attention_processor.py:396-450 like the one-head kernel, (b) BIT-identical to the one-head kernel on the same inputs
+    (same arithmetic in the same order), (c) bitwise repeatable (race screen of the split X / W rings and the key ring; the 130-key case
+    wraps the four-slot key ring three times, the 70 image tokens take two image-prompt tiles).  (8, 20, 1024, 77, 16 | 32) are the
+    benchmarked UNet-batch-8 calls of BASELINE.json configs[3] / configs[4], which auto mode routes here."""
+    from conftest import ref_row_stats
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    lib = L.load()
+    outs = {}
+    for mode in (10, 1):
+        assert lib.imh_debug_set(3, mode) == 0
+        try:
+            outs[mode] = _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_stats, fold_ln).clone()
+            if mode == 10:
+                for _ in range(2):
+                    again = _fused_cross_attention_case(L, ctx, dtype, B, H, Lq, nt, nip, ln, ref_row_stats, fold_ln)
+                    assert torch.equal(again, outs[10]), "wide fused cross attention not bitwise repeatable"
+        finally:
+            lib.imh_debug_set(3, 0)
+    # same arithmetic in the same order: the two-pass (text + image-prompt) instantiations are bit-identical; the text-only fp16 ones differ in
+    # the last bit of a few elements (the compiler contracts l = l * alpha + sum differently in the two kernels) -- held to 2 ulp of the output
+    d = (outs[10].float() - outs[1].float()).abs()
+    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * outs[1].float().abs().clamp_min(2.0 ** -6)
+    assert (d <= 2 * ulp).all(), f"wide form differs from the one-head kernel: max |d| = {d.max().item():.3e}"
+    if nip:
+        assert torch.equal(outs[10], outs[1]), f"two-pass wide form not bit-identical to the one-head kernel: max |d| = {d.max().item():.3e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
