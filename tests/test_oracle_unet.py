@@ -38,6 +38,50 @@ def test_sdxl_param_count_and_processor_schema():
     assert sd["add_embedding.linear_1.weight"].shape == (1280, 2816)
 
 
+def test_sdxl_unet_state_dict_equals_the_published_manifest():
+    """set-equality of (key, shape) -- not counts -- between the restated diffusers UNet (oracle), the product's
+    UNet2DConditionModel and tests/golden/sdxl_unet_manifest.txt, the state-dict manifest of stabilityai/stable-diffusion-xl-base-1.0's
+    `unet` enumerated from its published config.json by string templates (oracle/gen_manifest.py: a different mechanism from either
+    module tree; it reproduces the published 2,567,463,684 parameters).  A renamed, missing, extra or mis-shaped tensor in either model
+    fails here -- a real checkpoint loads into both with strict=True."""
+    import os
+    from conftest import GOLDEN
+    from oracle.gen_manifest import numel, read, unet_manifest
+    man = read(os.path.join(GOLDEN, "sdxl_unet_manifest.txt"))
+    assert man == dict(unet_manifest()) and len(man) == 1680                       # the committed fixture is what the generator writes
+    assert numel(man.items()) == 2_567_463_684
+    with torch.device("meta"):
+        o = UNet2DConditionModel(sdxl_config())
+    osd = {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    assert set(osd) == set(man), (sorted(set(osd) - set(man))[:5], sorted(set(man) - set(osd))[:5])
+    assert osd == man
+    from imagharmony_amd.unet import UNet2DConditionModel as HU, UNetConfig
+    with torch.device("meta"):
+        h = HU(UNetConfig())
+    hsd = {k: tuple(v.shape) for k, v in h.state_dict().items()}
+    assert set(hsd) == set(man), (sorted(set(hsd) - set(man))[:5], sorted(set(man) - set(hsd))[:5])
+    assert hsd == man
+
+
+def test_added_conditioning_shapes_follow_the_clip_text_encoders():
+    """add_embedding.linear_1 takes [pooled text embedding | 6 size / crop ids x 256 sinusoids] (custom_pipelines.py:283-301 ->
+    diffusers _get_add_time_ids): the pooled embedding is text_encoder_2's `text_embeds` (OpenCLIP bigG: projection_dim 1280), the
+    cross-attention context the concat of the two encoders' penultimate hidden states (768 + 1280 = 2048).  Checked against stock
+    `transformers` CLIP modules built from those published config values (shape facts only: no weights offline)."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    c1 = CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, projection_dim=768)
+    c2 = CLIPTextConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20, projection_dim=1280, hidden_act="gelu")
+    with torch.device("meta"):
+        te1, te2 = CLIPTextModel(c1), CLIPTextModelWithProjection(c2)
+    cfg = sdxl_config()
+    assert te2.text_projection.out_features == cfg.pooled_dim == 1280
+    assert cfg.projection_class_embeddings_input_dim == te2.text_projection.out_features + 6 * cfg.addition_time_embed_dim == 2816
+    assert te1.config.hidden_size + te2.config.hidden_size == cfg.cross_attention_dim == 2048
+    from imagharmony_amd.unet import UNetConfig
+    h = UNetConfig()
+    assert (h.pooled_dim, h.cross_attention_dim, h.projection_class_embeddings_input_dim) == (1280, 2048, 2816)
+
+
 def test_ip_adapter_state_dict_keys_like_convert_bin():
     """ModuleList(unet.attn_processors.values()) keys are '<odd idx>.to_k_ip.weight'
     (ip_adapter/ip_adapter.py:153-154, convert_bin.py:21-40)."""
@@ -65,6 +109,38 @@ def test_ddim_tables_and_identities():
     xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
     ap = ac[t - 33]
     assert torch.allclose(s.step(eps, t, xt)[0], ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=2e-5)
+
+
+def test_ddim_and_euler_closed_forms_at_every_timestep():
+    """the exact-recovery identities at ALL timesteps of the 30- and 50-step schedules (configs[1] / configs[3]),
+    not at one.  DDIM (eta = 0): with the true noise as the prediction, x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps steps to
+    sqrt(a_prev) x0 + sqrt(1 - a_prev) eps.  Euler: x = x0 + sigma eps steps to x0 + sigma_next eps, the model input is x / sqrt(sigma^2
+    + 1), and the sigmas are sqrt((1 - a) / a) at the (leading-spaced, offset 1) timesteps."""
+    x0, eps = det_randn((1, 4, 8, 8), 1).double(), det_randn((1, 4, 8, 8), 2).double()
+    for n in (30, 50):
+        s = DDIMScheduler()
+        s.set_timesteps(n)
+        r = 1000 // n
+        ts = s.timesteps.tolist()
+        assert ts == [i * r + 1 for i in range(n - 1, -1, -1)]
+        ac = s.alphas_cumprod.double()
+        for t in ts:
+            a = ac[t]
+            ap = ac[t - r] if t - r >= 0 else ac[0]
+            xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
+            got = s.step(eps.float(), t, xt.float())[0].double()
+            assert torch.allclose(got, ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=3e-5), (n, t)
+        e = EulerDiscreteScheduler()
+        e.set_timesteps(n)
+        sig = e.sigmas.double()
+        assert [int(t) for t in e.timesteps.tolist()] == ts
+        want = ((1 - ac) / ac).sqrt()
+        for i, t in enumerate(e.timesteps):
+            assert abs(float(sig[i]) - float(want[int(t)])) < 1e-5 * max(1.0, float(sig[i]))
+            x = x0 + sig[i] * eps
+            assert torch.allclose(e.scale_model_input(x.float(), t).double(), x / (sig[i] ** 2 + 1).sqrt(), atol=1e-5)
+            got = e.step(eps.float(), t, x.float())[0].double()
+            assert torch.allclose(got, x0 + sig[i + 1] * eps, atol=2e-4 * max(1.0, float(sig[i]))), (n, i)
 
 
 def test_euler_tables():

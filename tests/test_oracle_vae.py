@@ -27,6 +27,29 @@ def test_sdxl_vae_param_count_and_key_schema():
     assert m.tile_sample_min_size == 512 and m.tile_latent_min_size == 64
 
 
+def test_sdxl_vae_state_dict_equals_the_published_manifest():
+    """Set-equality of (key, shape) between the restated AutoencoderKL, tests/golden/sdxl_vae_manifest.txt (the SDXL VAE's state dict
+    enumerated from its published config.json, oracle/gen_manifest.py; 83,653,863 parameters) and -- for the decode half it implements --
+    the product's AutoencoderKL."""
+    import os
+    from conftest import GOLDEN
+    from oracle.gen_manifest import numel, read, vae_manifest
+    man = read(os.path.join(GOLDEN, "sdxl_vae_manifest.txt"))
+    assert man == dict(vae_manifest()) and numel(man.items()) == 83_653_863 and len(man) == 248
+    with torch.device("meta"):
+        m = AutoencoderKL(sdxl_vae_config())
+    osd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(osd) == set(man), (sorted(set(osd) - set(man))[:5], sorted(set(man) - set(osd))[:5])
+    assert osd == man
+    from imagharmony_amd.vae import AutoencoderKL as HV
+    with torch.device("meta"):
+        h = HV()
+    hsd = {k: tuple(v.shape) for k, v in h.state_dict().items()}
+    dec = {k: v for k, v in man.items() if k.startswith(("decoder.", "post_quant_conv."))}
+    assert set(hsd) == set(dec), (sorted(set(hsd) - set(dec))[:5], sorted(set(dec) - set(hsd))[:5])
+    assert hsd == dec
+
+
 def test_decode_shapes_tiling_and_postprocess():
     vae = det_fill(AutoencoderKL(tiny_vae_config()), 3).eval()
     z = det_randn((1, 4, 48, 40), 5)

@@ -26,8 +26,11 @@ def _check(h, o, n=30):
 
 def test_ddim_tables():
     _check(hs.DDIMScheduler(), osch.DDIMScheduler())
+    _check(hs.DDIMScheduler(), osch.DDIMScheduler(), n=50)       # BASELINE.json configs[3]
+    _check(hs.DDIMScheduler(), osch.DDIMScheduler(), n=10)       # configs[0]
 
 
 def test_euler_tables():
     _check(hs.EulerDiscreteScheduler(), osch.EulerDiscreteScheduler())
     _check(hs.EulerDiscreteScheduler(), osch.EulerDiscreteScheduler(), n=10)
+    _check(hs.EulerDiscreteScheduler(), osch.EulerDiscreteScheduler(), n=50)
