@@ -761,27 +761,35 @@ def main():
         if world == 1 and a.stacked > 1:        # same "extras" switch: the step right after the path, never in `value`
             try:
                 from imagharmony_amd.vae import AutoencoderKL, decode_latents
-                vae = AutoencoderKL().init_random_(1).to(device, dtype)
                 zl = out[:1].float() * 0.13025
-                ms_v = {}
-                for tiled in (False, True):
-                    vae.enable_tiling(tiled)
-                    img = decode_latents(vae, zl)
-                    torch.cuda.synchronize(device)
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        img = decode_latents(vae, zl)
-                    torch.cuda.synchronize(device)
-                    ms_v["tiled" if tiled else "untiled"] = (time.perf_counter() - t1) / 3 * 1e3
-                res["vae_decode"] = {"ms_per_image": ms_v, "outputs_finite": bool(torch.isfinite(img).all().item()),
-                                     "note": "SDXL VAE decoder 128x128 latent -> 1024x1024 image on the HIP kernels (random weights), "
-                                             "eager launches; not part of `value`"}
                 per_img = dt / images
-                res["value_with_decode"] = {
-                    "untiled": 1.0 / (per_img + ms_v["untiled"] * 1e-3), "tiled": 1.0 / (per_img + ms_v["tiled"] * 1e-3), "unit": "images/sec",
-                    "note": "decoded images per second = `value`'s denoise time + the measured VAE decode of the same latent, serially on this "
-                            "GPU (the reference returns PIL images: custom_pipelines.py:365-386, test.py:73 enables VAE tiling)"}
-                del vae
+                res["vae_decode"], res["value_with_decode"] = {}, {}
+                # (a) the reference's precision: a float16 VAE is upcast and decoded in fp32 (custom_pipelines.py:366-372) -> csrc/f32.hip;
+                # (b) opt-in: a bfloat16 module decodes in bf16 on the UNet's own kernels (the reference would not upcast it either)
+                for label, mdt, prec in (("fp32_reference_precision", torch.float16, "fp32"), ("bf16_native", dtype, "native")):
+                    vae = AutoencoderKL().init_random_(1).to(device, mdt)
+                    assert vae.precision_for() == prec
+                    ms_v = {}
+                    for tiled in (False, True):
+                        vae.enable_tiling(tiled)
+                        img = decode_latents(vae, zl)
+                        torch.cuda.synchronize(device)
+                        t1 = time.perf_counter()
+                        for _ in range(3):
+                            img = decode_latents(vae, zl)
+                        torch.cuda.synchronize(device)
+                        ms_v["tiled" if tiled else "untiled"] = (time.perf_counter() - t1) / 3 * 1e3
+                    res["vae_decode"][label] = {"ms_per_image": ms_v, "dtype": "f32" if prec == "fp32" else a.dtype, "module_dtype": str(mdt)[6:],
+                                                "outputs_finite": bool(torch.isfinite(img).all().item())}
+                    res["value_with_decode"][label] = {"untiled": 1.0 / (per_img + ms_v["untiled"] * 1e-3), "tiled": 1.0 / (per_img + ms_v["tiled"] * 1e-3),
+                                                       "unit": "images/sec", "decode_dtype": "f32" if prec == "fp32" else a.dtype}
+                    del vae
+                res["vae_decode"]["note"] = ("SDXL VAE decoder 128x128 latent -> 1024x1024 image on the HIP kernels (random weights), eager launches; not part of "
+                                             "`value`.  fp32_reference_precision = what the reference runs (it upcasts the float16 VAE before vae.decode): fp32 "
+                                             "activations / weights / arithmetic (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate); bf16_native = the opt-in 16-bit decode")
+                res["value_with_decode"]["note"] = ("decoded images per second = `value`'s denoise time + the measured VAE decode of the same latent, serially on this GPU "
+                                                    "(the reference returns PIL images: custom_pipelines.py:365-386, test.py:73 enables VAE tiling); quote the "
+                                                    "fp32_reference_precision entry as 'decoded like the reference'")
             except Exception as e:      # noqa: BLE001
                 res["vae_decode"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and a.stacked > 1:        # same "extras" switch: SURVEY.md 8(a5), once per image, never in `value`

@@ -281,6 +281,17 @@ int imh_layernorm(const imh_norm_args* a, void* stream) {
 
 int imh_elementwise(int op, const imh_ew_args* a, void* stream) { return do_ew(op, a, (hipStream_t)stream); }
 
+int imh_f32(int op, const imh_f32_args* a, void* stream) {
+    if (!a) { set_error("imh_f32: null args"); return IMH_ERR_ARG; }
+    F32Params p;
+    p.X = a->X; p.W = a->W; p.Y = a->Y; p.bias = a->bias; p.residual = a->residual; p.gamma = a->gamma; p.beta = a->beta; p.ws = a->ws;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr;
+    p.conv = a->conv; p.H = a->H; p.Wd = a->Wd; p.Cin = a->Cin; p.Ho = a->Ho; p.Wo = a->Wo; p.up = a->up;
+    p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.nblk = a->nblk; p.silu = a->silu;
+    p.eps = a->eps; p.scale = a->scale;
+    return f32_launch(op, p, (hipStream_t)stream);
+}
+
 imh_plan* imh_plan_create(void) { return new (std::nothrow) imh_plan(); }
 void imh_plan_destroy(imh_plan* p) {
     if (!p) return;

@@ -141,6 +141,18 @@ int groupnorm_stats_blocks(int HW, int C);
 int groupnorm_stats_sub(int C, int groups);
 int layernorm_launch(const NormParams& p, int dtype, hipStream_t stream);
 
+// fp32 (reference-precision) kernels of the VAE decode tail (f32.hip).  op 0: GEMM / conv3x3 (X, W, Y, bias, residual; conv fields);
+// 1: GroupNorm statistics (X [B, HW, C] -> ws [B, nblk, groups, 2]); 2: table (ws, gamma, beta -> Y [B, C, 2]); 3: apply (X, ws = table -> Y);
+// 4: row softmax (X [M, ldx] -> Y [M, ldy], N columns, scale)
+struct F32Params {
+    const float* X; const float* W; float* Y; const float* bias; const float* residual; const float* gamma; const float* beta; float* ws;
+    int M, N, K, ldx, ldw, ldy, ldr;
+    int conv, H, Wd, Cin, Ho, Wo, up;
+    int B, HW, C, groups, nblk, silu;
+    float eps, scale;
+};
+int f32_launch(int op, const F32Params& p, hipStream_t stream);
+
 struct EwParams {
     const void* a;
     const void* b;

@@ -544,6 +544,76 @@ class Ctx:
             self.free(keep_st[0])
         return out
 
+    # ------------------------------------------------------------------ fp32 (reference-precision) ops of the VAE decode tail (csrc/f32.hip)
+    def _f32(self, op, a, descr):
+        if self.record:
+            raise L.ImhError(f"{descr}: the fp32 ops run eagerly (once per image); they are not plan ops")
+        L.check(self.lib.imh_f32(op, C.byref(a), self.stream()), descr)
+
+    def f32_gemm(self, x, w, bias=None, residual=None, out=None, M=None, N=None, K=None, ldx=None, ldw=None, descr="f32.gemm"):
+        """y[M, N] = x[M, K] @ w[N, K]^T (+ bias) (+ residual), everything fp32 (v_mfma_f32_32x32x2_f32); K % 16 == 0"""
+        for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (residual, "residual"), (out, "out")):
+            self._chk(t, f"{descr}.{n}", torch.float32)
+        M = M if M is not None else x.shape[0]
+        K = K if K is not None else x.shape[1]
+        N = N if N is not None else w.shape[0]
+        if out is None:
+            out = self.new(M, N, dtype=torch.float32)
+        a = L.F32Args()
+        a.X, a.W, a.Y, a.bias, a.residual = x.data_ptr(), w.data_ptr(), out.data_ptr(), self._p(bias), self._p(residual)
+        a.M, a.N, a.K = M, N, K
+        a.ldx = ldx if ldx is not None else x.stride(0)
+        a.ldw = ldw if ldw is not None else w.stride(0)
+        a.ldy = out.stride(0)
+        a.ldr = residual.stride(0) if residual is not None else 0
+        self._f32(L.F32_GEMM, a, descr)
+        return out
+
+    def f32_conv3x3(self, x, w, bias=None, residual=None, up=0, descr="f32.conv3x3"):
+        """x NHWC [B, H, W, Cin] fp32, w packed [Cout, 9 Cin] fp32 -> [B, H << up, W << up, Cout]; stride 1, padding 1, nearest x2 fused"""
+        for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (residual, "residual")):
+            self._chk(t, f"{descr}.{n}", torch.float32)
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = H << up, W << up
+        if not x.is_contiguous() or not w.is_contiguous() or w.shape[1] != 9 * Cin:
+            raise L.ImhError(f"{descr}: x must be contiguous NHWC and w packed [Cout, 9*Cin]")
+        out = self.new(B, Ho, Wo, Cout, dtype=torch.float32)
+        a = L.F32Args()
+        a.X, a.W, a.Y, a.bias, a.residual = x.data_ptr(), w.data_ptr(), out.data_ptr(), self._p(bias), self._p(residual)
+        a.M, a.N, a.K = B * Ho * Wo, Cout, 9 * Cin
+        a.ldx, a.ldw, a.ldy, a.ldr = Cin, 9 * Cin, Cout, (residual.stride(-2) if residual is not None else 0)
+        a.conv, a.H, a.Wd, a.Cin, a.Ho, a.Wo, a.up = 1, H, W, Cin, Ho, Wo, up
+        self._f32(L.F32_GEMM, a, descr)
+        return out
+
+    def f32_groupnorm(self, x, gamma, beta, groups, eps, silu=False, descr="f32.groupnorm"):
+        """x [B, HW, C] fp32 -> GroupNorm(groups)(+ SiLU), fp32; statistics as shifted (sum, M2) partials merged in double"""
+        for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta")):
+            self._chk(t, f"{descr}.{n}", torch.float32)
+        B, HW, Cc = x.shape
+        nblk = max(1, (HW + 2047) // 2048)
+        part = self.new(B, nblk, groups, 2, dtype=torch.float32)
+        tab = self.new(B, Cc, 2, dtype=torch.float32)
+        y = self.new(B, HW, Cc, dtype=torch.float32)
+        a = L.F32Args()
+        a.X, a.ws, a.B, a.HW, a.C, a.groups, a.nblk, a.eps, a.silu = x.data_ptr(), part.data_ptr(), B, HW, Cc, groups, nblk, float(eps), int(silu)
+        self._f32(L.F32_GN_STATS, a, descr + ".stats")
+        a.gamma, a.beta, a.Y = gamma.data_ptr(), beta.data_ptr(), tab.data_ptr()
+        self._f32(L.F32_GN_TABLE, a, descr + ".table")
+        a.ws, a.Y = tab.data_ptr(), y.data_ptr()
+        self._f32(L.F32_GN_APPLY, a, descr + ".apply")
+        self.free(part); self.free(tab)
+        return y
+
+    def f32_softmax(self, a_, out, scale, descr="f32.softmax"):
+        """out[r, :] = softmax(scale * a_[r, :]), fp32 rows"""
+        self._chk(a_, descr + ".a", torch.float32); self._chk(out, descr + ".out", torch.float32)
+        a = L.F32Args()
+        a.X, a.Y, a.M, a.N, a.ldx, a.ldy, a.scale = a_.data_ptr(), out.data_ptr(), a_.shape[0], a_.shape[1], a_.stride(0), out.stride(0), float(scale)
+        self._f32(L.F32_SOFTMAX, a, descr)
+        return out
+
     def attention_small(self, q, k, v, B, H, Lq, Lk, dq, dv, scale, out=None, descr="attention_small"):
         """q [B*Lq, H*dq], k [B*Lk, H*dq], v [B*Lk, H*dv] row-major (any row stride) -> [B*Lq, H*dv]"""
         if out is None:

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _EXP_PATH = os.path.join(_HERE, "..", "tools", "tmp_libs", "libimh_hip_experimental.so")
 LIB_PATH = os.environ.get("IMH_LIB_PATH") or (_EXP_PATH if os.environ.get("IMH_EXPERIMENTAL") == "1" else os.path.join(_HERE, "libimh_hip.so"))
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 IMH_DT_BF16, IMH_DT_F16 = 0, 1
 GF_GEGLU, GF_ACT_GELU, GF_ACT_SILU, GF_VT_PERM, GF_OUT_F32, GF_LN_ROW, GF_LN_COL = 1, 2, 4, 8, 16, 32, 64
 OP_GEMM, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_EW, OP_ATTN_SMALL, OP_GEMM_DUAL, OP_XATTN = 0, 1, 2, 3, 4, 5, 6, 7
@@ -94,6 +94,16 @@ class EwArgs(C.Structure):
                 ("f0", _f32), ("f1", _f32), ("f2", _f32), ("f3", _f32), ("dtype", _i32)]
 
 
+class F32Args(C.Structure):
+    _fields_ = [("X", _vp), ("W", _vp), ("Y", _vp), ("bias", _vp), ("residual", _vp), ("gamma", _vp), ("beta", _vp), ("ws", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("ldx", _i32), ("ldw", _i32), ("ldy", _i32), ("ldr", _i32),
+                ("conv", _i32), ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("up", _i32),
+                ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("nblk", _i32), ("silu", _i32),
+                ("eps", _f32), ("scale", _f32)]
+
+
+F32_GEMM, F32_GN_STATS, F32_GN_TABLE, F32_GN_APPLY, F32_SOFTMAX = range(5)
+
 # every symbol include/imh.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("imh_abi_version", C.c_int, []),
@@ -115,6 +125,7 @@ SYMBOLS = [
     ("imh_groupnorm_stats_sub", C.c_int, [C.c_int, C.c_int]),
     ("imh_layernorm", C.c_int, [C.POINTER(NormArgs), _vp]),
     ("imh_elementwise", C.c_int, [C.c_int, C.POINTER(EwArgs), _vp]),
+    ("imh_f32", C.c_int, [C.c_int, C.POINTER(F32Args), _vp]),
     ("imh_plan_create", _vp, []),
     ("imh_plan_destroy", None, [_vp]),
     ("imh_plan_add", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),

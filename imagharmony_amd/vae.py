@@ -3,9 +3,18 @@
 because the SDXL VAE overflows in fp16; test.py:73 turns tiling on) and ``image_processor.postprocess`` (:386).
 
 Same parameter names as diffusers' ``AutoencoderKL`` (``decoder.*``, ``post_quant_conv.*``; encoder keys are accepted
-and ignored), so a real SDXL VAE state dict drops in.  Compute: bf16 by default (fp32 range, no overflow), NHWC
-activations, the UNet's own kernels -- GroupNorm(+SiLU), implicit-GEMM conv3x3 (fused nearest-x2 upsampling), GEMM --
-plus a materialised single-head attention for the mid block (scores GEMM -> fp32 row softmax -> PV GEMM: one head of
+and ignored), so a real SDXL VAE state dict drops in.  Two compute modes, chosen like the reference chooses
+(``needs_upcasting = vae.dtype == float16 and vae.config.force_upcast`` -> ``upcast_vae()``, custom_pipelines.py:366-372):
+
+* **fp32** (round 6; a float16 module with ``force_upcast``, or a float32 module): fp32 activations, fp32 weights (the stored
+  weights upcast exactly, as ``vae.to(float32)`` does) and fp32 arithmetic on the fp32 kernels of csrc/f32.hip
+  (``v_mfma_f32_32x32x2_f32`` implicit-GEMM conv3x3 / GEMM, GroupNorm statistics merged in double, row softmax) -- the
+  reference's precision, no fp16 overflow; ~0.1 s per 1024^2 image (the fp32 matrix rate is 1/16 of bf16's).
+* **native** (a bfloat16 module -- which the reference does not upcast either -- or ``precision="native"``): NHWC activations
+  in the module's 16-bit dtype on the UNet's own kernels -- GroupNorm(+SiLU), implicit-GEMM conv3x3 (fused nearest-x2
+  upsampling), GEMM -- 18 ms per image, 1e-2 rel-RMS from the fp32 result in bf16.
+
+Both run a materialised single-head attention for the mid block (scores GEMM -> fp32 row softmax -> PV GEMM: one head of
 width 512 does not fit the head_dim-64 flash kernel, and it runs once per image).  Tiled decoding follows diffusers'
 ``tiled_decode`` (overlapping 64x64-latent tiles, linear blends).  Host-side torch is plumbing only: channel padding
 of the 4-channel latent, the tile blends / concatenation, and the final NHWC->image conversion.
@@ -194,6 +203,86 @@ def _pad_1x1(conv, ctx, cpad=64):
     return c[1], c[2]
 
 
+# ---- fp32 (reference-precision) decode: the same graph on csrc/f32.hip --------------------------------------------------
+def _f32_cached(mod, name, build, *src):
+    """fp32 copy of a module's (packed / padded) parameter on the device, rebuilt when the source changes (in place or re-assigned)"""
+    key = (_vkey(*src), str(src[0].device))
+    c = getattr(mod, name, None)
+    if c is None or c[0] != key:
+        c = (key, build())
+        setattr(mod, name, c)
+    return c[1]
+
+
+def _f32_conv_w(conv, cin_pad=0):
+    """[Cout, Cin, 3, 3] -> packed fp32 [Cout, 9 * Cin'] (K index = (ky*3+kx)*Cin' + c), Cin zero-padded to cin_pad"""
+    def build():
+        w = conv.weight.detach().float()
+        if cin_pad and cin_pad > w.shape[1]:
+            wp = torch.zeros(w.shape[0], cin_pad, 3, 3, dtype=torch.float32, device=w.device)
+            wp[:, :w.shape[1]] = w
+            w = wp
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    return _f32_cached(conv, "_imh_f32_w", build, conv.weight)
+
+
+def _f32_lin_w(lin):
+    return _f32_cached(lin, "_imh_f32_w", lambda: lin.weight.detach().float().reshape(lin.weight.shape[0], -1).contiguous(), lin.weight)
+
+
+def _f32_vec(mod, attr="bias"):
+    t = getattr(mod, attr)
+    return _f32_cached(mod, "_imh_f32_" + attr, lambda: t.detach().float().contiguous(), t)
+
+
+def _gn32(ctx, norm, x, groups, silu, descr):
+    B, H, W, C_ = x.shape
+    return ctx.f32_groupnorm(x.view(B, H * W, C_), _f32_vec(norm, "weight"), _f32_vec(norm, "bias"), groups, norm.eps, silu=silu,
+                             descr=descr).view(B, H, W, C_)
+
+
+def _res32(ctx, r, x):
+    B, H, W, Cin = x.shape
+    n = _gn32(ctx, r.norm1, x, r.groups, True, "vae32.res.norm1")
+    h = ctx.f32_conv3x3(n, _f32_conv_w(r.conv1), bias=_f32_vec(r.conv1), descr="vae32.res.conv1")
+    ctx.free(n)
+    n = _gn32(ctx, r.norm2, h, r.groups, True, "vae32.res.norm2")
+    ctx.free(h)
+    if r.conv_shortcut is not None:
+        sc = ctx.f32_gemm(x.view(B * H * W, Cin), _f32_lin_w(r.conv_shortcut), bias=_f32_vec(r.conv_shortcut), descr="vae32.res.shortcut")
+    else:
+        sc = x.view(B * H * W, Cin)
+    out = ctx.f32_conv3x3(n, _f32_conv_w(r.conv2), bias=_f32_vec(r.conv2), residual=sc, descr="vae32.res.conv2")
+    ctx.free(n)
+    if r.conv_shortcut is not None:
+        ctx.free(sc)
+    ctx.free(x)
+    return out
+
+
+def _attn32(ctx, at, x):
+    B, H, W, C_ = x.shape
+    Lq = H * W
+    n = _gn32(ctx, at.group_norm, x, at.groups, False, "vae32.attn.norm").view(B * Lq, C_)
+    q = ctx.f32_gemm(n, _f32_lin_w(at.to_q), bias=_f32_vec(at.to_q), descr="vae32.attn.to_q")
+    k = ctx.f32_gemm(n, _f32_lin_w(at.to_k), bias=_f32_vec(at.to_k), descr="vae32.attn.to_k")
+    # V^T = Wv n^T (swapped operands) feeds the PV GEMM as its [N, K] operand; softmax rows sum to 1, so the to_v bias is added once after PV
+    vt = ctx.f32_gemm(_f32_lin_w(at.to_v), n, descr="vae32.attn.to_v^T")                      # [C, B*L]
+    ctx.free(n)
+    o = ctx.new(B * Lq, C_, dtype=torch.float32)
+    sc = ctx.new(Lq, Lq, dtype=torch.float32)
+    for b in range(B):
+        qb, kb = q[b * Lq:(b + 1) * Lq], k[b * Lq:(b + 1) * Lq]
+        ctx.f32_gemm(qb, kb, out=sc, descr="vae32.attn.scores")
+        ctx.f32_softmax(sc, sc, C_ ** -0.5, descr="vae32.attn.softmax")                        # in place (a row is read before it is written)
+        ctx.f32_gemm(sc, vt[:, b * Lq:(b + 1) * Lq], out=o[b * Lq:(b + 1) * Lq], bias=_f32_vec(at.to_v), N=C_, K=Lq, ldw=B * Lq,
+                     descr="vae32.attn.pv")
+    ctx.free(sc); ctx.free(q); ctx.free(k); ctx.free(vt)
+    out = ctx.f32_gemm(o, _f32_lin_w(at.to_out[0]), bias=_f32_vec(at.to_out[0]), residual=x.view(B * Lq, C_), descr="vae32.attn.to_out")
+    ctx.free(o); ctx.free(x)
+    return out.view(B, H, W, C_)
+
+
 class AutoencoderKL(nn.Module):
     """decode-only AutoencoderKL.  ``decode(z)`` returns the image tensor [B, 3, 8h, 8w] (fp32, roughly [-1, 1])."""
 
@@ -238,11 +327,59 @@ class AutoencoderKL(nn.Module):
         return self.decoder.conv_in.weight.dtype
 
     # -- compute --
-    def _decode_tile(self, z):
+    def precision_for(self, precision=None):
+        """'fp32' | 'native': the reference's rule (custom_pipelines.py:366-372) unless the caller names one"""
+        precision = precision or getattr(self, "precision", "auto")
+        if precision == "auto":
+            dt = self.dtype
+            precision = "fp32" if dt == torch.float32 or (dt == torch.float16 and self.config.force_upcast) else "native"
+        if precision not in ("fp32", "native"):
+            raise ValueError(f"precision {precision!r} (expected 'auto', 'fp32' or 'native')")
+        return precision
+
+    def _decode_tile_f32(self, z):
+        """z: [B, 4, h, w] fp32 on the device -> [B, 3, 8h, 8w] fp32, every activation and every product in fp32"""
+        dev = z.device
+        ctx = Ctx(dev, torch.bfloat16)                                           # (pool / stream only: every tensor below is fp32)
+        B, _, h, w = z.shape
+        d = self.decoder
+        zp = torch.zeros(B, h, w, 16, dtype=torch.float32, device=dev)           # plumbing: NHWC, channels padded to the K step of 16
+        zp[..., :z.shape[1]] = z.permute(0, 2, 3, 1)
+        pq = self.post_quant_conv
+
+        def build_pq():
+            wq = torch.zeros(16, 16, dtype=torch.float32, device=dev)
+            wq[:pq.weight.shape[0], :pq.weight.shape[1]] = pq.weight.detach().float().view(pq.weight.shape[0], -1)
+            bq = torch.zeros(16, dtype=torch.float32, device=dev)
+            bq[:pq.bias.shape[0]] = pq.bias.detach().float()
+            return wq, bq
+        wq, bq = _f32_cached(pq, "_imh_f32_w", build_pq, pq.weight, pq.bias)
+        t = ctx.f32_gemm(zp.view(B * h * w, 16), wq, bias=bq, descr="vae32.post_quant").view(B, h, w, 16)
+        x = ctx.f32_conv3x3(t, _f32_conv_w(d.conv_in, cin_pad=16), bias=_f32_vec(d.conv_in), descr="vae32.conv_in")
+        ctx.free(t)
+        x = _res32(ctx, d.mid_block.resnets[0], x)
+        x = _attn32(ctx, d.mid_block.attentions[0], x)
+        x = _res32(ctx, d.mid_block.resnets[1], x)
+        for blk in d.up_blocks:
+            for r in blk.resnets:
+                x = _res32(ctx, r, x)
+            for u in getattr(blk, "upsamplers", []):
+                y = ctx.f32_conv3x3(x, _f32_conv_w(u.conv), bias=_f32_vec(u.conv), up=1, descr="vae32.upsample")    # nearest x2 fused
+                ctx.free(x)
+                x = y
+        n = _gn32(ctx, d.conv_norm_out, x, d.groups, True, "vae32.conv_norm_out")
+        ctx.free(x)
+        y = ctx.f32_conv3x3(n, _f32_conv_w(d.conv_out), bias=_f32_vec(d.conv_out), descr="vae32.conv_out")          # [B, 8h, 8w, 3]
+        ctx.free(n)
+        return y.permute(0, 3, 1, 2).contiguous()
+
+    def _decode_tile(self, z, precision="native"):
         """z: [B, 4, h, w] fp32 on the device -> [B, 3, 8h, 8w] fp32"""
+        if precision == "fp32":
+            return self._decode_tile_f32(z)
         dev, dt = z.device, self.dtype
         if dt not in (torch.bfloat16, torch.float16):
-            raise L.ImhError("the HIP VAE computes in bf16 (default) or fp16; cast the module")
+            raise L.ImhError("the native HIP VAE path computes in bf16 or fp16 (precision='fp32' runs any module in fp32)")
         ctx = Ctx(dev, dt)
         B, _, h, w = z.shape
         zp = torch.zeros(B, h, w, 64, dtype=dt, device=dev)                     # plumbing: NHWC, channels padded to 64
@@ -269,13 +406,13 @@ class AutoencoderKL(nn.Module):
         head = a.narrow(dim, a.shape[dim] - extent, extent) * (1 - wgt) + b.narrow(dim, 0, extent) * wgt
         return torch.cat([head, b.narrow(dim, extent, b.shape[dim] - extent)], dim)
 
-    def tiled_decode(self, z):
+    def tiled_decode(self, z, precision="native"):
         overlap = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
         extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
         limit = self.tile_sample_min_size - extent
         rows = []
         for i in range(0, z.shape[2], overlap):
-            rows.append([self._decode_tile(z[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size].contiguous())
+            rows.append([self._decode_tile(z[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size].contiguous(), precision)
                          for j in range(0, z.shape[3], overlap)])
         out_rows = []
         for i, row in enumerate(rows):
@@ -291,16 +428,19 @@ class AutoencoderKL(nn.Module):
         return torch.cat(out_rows, dim=2)
 
     @torch.no_grad()
-    def decode(self, z):
+    def decode(self, z, precision=None):
+        """precision: None / 'auto' = the reference's rule (fp32 for a float16 module with force_upcast or a float32 module, the module's
+        16-bit dtype for bfloat16); 'fp32' / 'native' force a mode"""
+        precision = self.precision_for(precision)
         z = z.to(self.decoder.conv_in.weight.device, torch.float32)
         if self.use_tiling and (z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size):
-            return self.tiled_decode(z)
-        return self._decode_tile(z)
+            return self.tiled_decode(z, precision)
+        return self._decode_tile(z, precision)
 
 
-def decode_latents(vae: AutoencoderKL, latents):
+def decode_latents(vae: AutoencoderKL, latents, precision=None):
     """custom_pipelines.py:365-379"""
-    return vae.decode(latents.float() / vae.config.scaling_factor)
+    return vae.decode(latents.float() / vae.config.scaling_factor, precision=precision)
 
 
 def postprocess(image, output_type="pil"):

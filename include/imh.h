@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMH_ABI_VERSION 8
+#define IMH_ABI_VERSION 9
 
 enum imh_status {
     IMH_OK = 0,
@@ -353,6 +353,36 @@ typedef struct imh_ew_args {
 } imh_ew_args;
 
 int imh_elementwise(int op, const imh_ew_args* a, void* stream);
+
+/* ---- fp32 (reference-precision) kernels for the VAE decode tail -------------------------------
+ * ip_adapter/custom_pipelines.py:365-377 upcasts the SDXL VAE to fp32 before `vae.decode` (it overflows in fp16): this entry keeps
+ * fp32 activations, fp32 weights and fp32 arithmetic (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate).  All pointers fp32.
+ *   IMH_F32_GEMM     Y[M, N] = X[M, K] W[N, K]^T (+ bias[n]) (+ residual[m, n]); K % 16 == 0.  conv == 1: 3x3, padding 1, stride 1,
+ *                    optional nearest x2 upsampling of the input (up = 1), NHWC input [B, H, Wd, Cin], weights [Cout][ky][kx][Cin],
+ *                    K = 9 Cin, Cin % 16 == 0, M = B Ho Wo.  Replaces diffusers AutoencoderKL's Conv2d / Linear / Upsample2D.
+ *   IMH_F32_GN_STATS X [B, HW, C] -> ws [B, nblk, groups, 2] = (mean, M2) per pixel block and group   (diffusers GroupNorm(32, eps 1e-6))
+ *   IMH_F32_GN_TABLE ws, gamma, beta -> Y [B, C, 2] = (gamma rstd, beta - mean gamma rstd), merged in double in a fixed order
+ *   IMH_F32_GN_APPLY Y = silu?(X scale + shift), ws = the table
+ *   IMH_F32_SOFTMAX  Y[r, 0:N] = softmax(scale X[r, 0:N]), M rows (the mid-block attention's materialised scores)
+ */
+enum imh_f32_op { IMH_F32_GEMM = 0, IMH_F32_GN_STATS = 1, IMH_F32_GN_TABLE = 2, IMH_F32_GN_APPLY = 3, IMH_F32_SOFTMAX = 4 };
+
+typedef struct imh_f32_args {
+    const float* X;
+    const float* W;
+    float* Y;
+    const float* bias;
+    const float* residual;
+    const float* gamma;
+    const float* beta;
+    float* ws;
+    int32_t M, N, K, ldx, ldw, ldy, ldr;
+    int32_t conv, H, Wd, Cin, Ho, Wo, up;
+    int32_t B, HW, C, groups, nblk, silu;
+    float eps, scale;
+} imh_f32_args;
+
+int imh_f32(int op, const imh_f32_args* a, void* stream);
 
 /* ---- plans: a recorded sequence of the calls above, replayed from C++ (one UNet forward is
  * ~1000 launches; Python would be the bottleneck) and optionally captured into a hipGraph. ---- */

@@ -93,6 +93,26 @@ def test_fullsize_vae_decode_1024():
     assert postprocess(t, "pil")[0].size == (1024, 1024)
 
 
+def test_fullsize_vae_decode_1024_reference_precision():
+    """the same decode at the reference's precision (a float16 module is upcast: fp32 activations / weights / arithmetic on csrc/f32.hip,
+    incl. the 16384 x 16384 fp32 score matrix of the mid-block attention): finite, deterministic, tiled and untiled, and the bf16 decode of
+    the same weights agrees with it to bf16's precision"""
+    from imagharmony_amd.vae import AutoencoderKL, decode_latents
+    vae = AutoencoderKL().init_random_(1).to(DEV, torch.float16)
+    assert vae.precision_for() == "fp32"
+    lat = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0)).to(DEV) * 0.13025
+    a = decode_latents(vae, lat)
+    assert a.shape == (1, 3, 1024, 1024) and a.dtype == torch.float32 and torch.isfinite(a).all()
+    assert torch.equal(a, decode_latents(vae, lat))
+    vae.enable_tiling()
+    t = decode_latents(vae, lat)
+    assert t.shape == a.shape and torch.isfinite(t).all() and not torch.equal(t, a)
+    vae.enable_tiling(False)
+    b = decode_latents(vae.to(torch.bfloat16), lat)                 # bfloat16 module -> native 16-bit decode (weights rounded to bf16 as well)
+    rel = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
+    assert rel < 4e-2, rel
+
+
 @pytest.mark.parametrize("dtype,S,T,sched", [(torch.float16, 4, 16, "euler"), (torch.bfloat16, 4, 32, "ddim")])
 def test_fullsize_stacked_candidates_configs_3_and_4(dtype, S, T, sched):
     """BASELINE.json configs[3] (batch 4 per GPU, 16 Resampler tokens, fp16) and configs[4] (4 PNS candidates per GPU,

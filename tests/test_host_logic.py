@@ -30,7 +30,7 @@ def test_ctypes_structs_match_header_field_order():
     hdr = open(os.path.join(ROOT, "include", "imh.h")).read()
     for cname, struct in (("imh_gemm_args", lib.GemmArgs), ("imh_attn_args", lib.AttnArgs),
                           ("imh_norm_args", lib.NormArgs), ("imh_ew_args", lib.EwArgs),
-                          ("imh_small_attn_args", lib.SmallAttnArgs), ("imh_xattn_args", lib.XAttnArgs)):
+                          ("imh_small_attn_args", lib.SmallAttnArgs), ("imh_xattn_args", lib.XAttnArgs), ("imh_f32_args", lib.F32Args)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
