@@ -470,7 +470,7 @@ int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t s
                   "wrote the rows, or IMH_EW_ROW_STATS); there is no in-loop E[x^2] - mean^2 form");
         return IMH_ERR_ARG;
     }
-    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128) && (p.flags & GF_LN_ROW))) || conv)) {
+    if ((p.flags & (GF_LN_ROW | GF_LN_COL)) && (p.splits > 1 || (bm >= 256 && !((bm == 1464 || bm == 2464 || bm == 24128 || bm == 23256 || bm == 22128 || bm == 26256) && (p.flags & GF_LN_ROW))) || conv)) {
         set_error("gemm: folded LayerNorm needs a plain 64/128 tile or a wave-specialised variant (row form), splits == 1, no conv (bm=%d splits=%d conv=%d)", bm, p.splits, conv);
         return IMH_ERR_ARG;
     }

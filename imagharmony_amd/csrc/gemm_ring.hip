@@ -1045,6 +1045,11 @@ static int ring_typed(const GemmParams& p, int bm, int bn, hipStream_t stream) {
 }
 
 int gemm_ring_launch(const GemmParams& p, int dtype, int conv, int bm, int bn, hipStream_t stream) {
+    // the sixteen-wave 256 x 320 tile of ff.net.0 (gemm_w16.hip, round 6)
+    if (bm == 26256 && bn == 320) {
+        if (conv) { set_error("gemm: variant 26256 x 320 is a Linear-layer form"); return IMH_ERR_ARG; }
+        return gemm_w16_launch(p, dtype, stream);
+    }
 
     if (dtype == IMH_DT_BF16) return conv ? ring_typed<bf16_t, true>(p, bm, bn, stream) : ring_typed<bf16_t, false>(p, bm, bn, stream);
     if (dtype == IMH_DT_F16) return conv ? ring_typed<f16_t, true>(p, bm, bn, stream) : ring_typed<f16_t, false>(p, bm, bn, stream);

@@ -1,0 +1,218 @@
+// ff.net.0 (diffusers FeedForward / GEGLU behind norm3; call site ip_adapter/custom_pipelines.py:338-345) as ONE round of workgroups:
+// 256 x 320 output tiles on SIXTEEN waves.
+//
+// The launch is M = 2048 x N = 10240 x K = 1280: on the 256 x 160 wave-specialised tile (gemm_ring.hip, variant 23256) it is 512 workgroups =
+// two rounds at one per CU, each round paying its own prologue (2.7 us), K loop (19.5 us) and epilogue (5.3 us) -- 58.6 us warm, 22 % of the
+// UNet forward (profiles/r06_ws_timeline.txt).  The K loop of those launches runs at what a CU's vector-memory path delivers (53 KB per ~2000
+// cycles), so what shortens it is fewer operand bytes per FLOP: a 256 x 320 tile stages 73.7 KB per K tile for twice the MFMAs (36.9 KB per
+// 256 x 160 equivalent, -30 %), and M x N / (256 x 320) = 256 workgroups is exactly one round.
+//   * 16 waves as 4 (M) x 4 (N), wave tile 64 x 80 = 4 x 5 fragments of v_mfma_f32_16x16x32 -- the wave tile of the 23256 kernel's consumers --
+//     80 accumulator registers; 1024 threads hold a CU's whole register file at 128 registers each, so there are no dedicated producer
+//     waves and no second fragment set: four waves per SIMD hide each other's LDS latency and LDS-DMA issue instead.
+//   * two 73.7-KB stages (147 KB): tile t + 1 is in flight while tile t is consumed, one vmcnt(0) + s_barrier per K tile.
+//   * operands, swizzles, fragment maps and the folded-LayerNorm + GEGLU arithmetic are the 23256 kernel's (same order of operations per
+//     output element: results are bit-identical to it).
+// Only the launch it was built for: row-form folded LayerNorm with handed-over statistics (+ GEGLU), whole tiles, no residual / row-add.
+#include "imh_common.h"
+#include "imh_kernels.h"
+#include "imh_gemm_epilogue.h"
+#include "imh_lnstats.h"
+
+namespace imh {
+
+#ifndef W16_TIMING
+#define W16_TIMING 0
+#endif
+
+// (Measured and not kept, profiles/r06_w16_probe.txt: K tiles of 32 in FOUR 36.9-KB stages with counted vmcnt -- three half tiles in flight
+// across every barrier instead of one tile issued behind the barrier -- 59.2 vs 54.1 us: the K loop takes ~2250 cycles per 32 k either way
+// (1280 of MFMA).  It is not the LDS-DMA round trip: sixteen 64 x 80 wave tiles read every staged byte four times (144 KB of fragment reads per
+// 36.9 KB staged, twice the 23256 kernel's), each wave has registers for ONE weight fragment of look-ahead, and four waves per SIMD do not
+// cover the LDS latency that leaves exposed.)
+template <typename T>
+__global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 320, TM = 64, TN = 80, FM = 4, FN = 5;
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;       // 73,728 B
+    constexpr int NI = (BM + BN) / 8;                       // 72 LDS-DMA wave instructions per K tile: 32 token pieces, 40 weight pieces
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+#if W16_TIMING
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;
+    const int nkt = p.K / GEMM_BK;
+
+    // ---- staging: wave w issues pieces w, w + 16, w + 32, w + 48 (and w + 64 for w < 8); piece q = tile rows 8 q .. 8 q + 7, rows [0, 256) =
+    //      tokens, [256, 576) = weights.  The launcher guarantees whole tiles: no bounds, one base pointer per operand.
+    const int r0 = wave * 8 + (lane >> 3);                  // row of piece `wave`; piece wave + 16 k adds 128 k rows
+    const unsigned char* const xb = (const unsigned char*)p.X + ((size_t)(m0 + r0) * p.ldx) * sizeof(T) + stage_chunk_x(r0, lane) * 16;
+    const size_t xstride = (size_t)128 * p.ldx * sizeof(T);
+    const unsigned char* const wb = (const unsigned char*)p.W + (size_t)n0 * p.ldw * sizeof(T);
+    unsigned woffk[3];                                      // weight pieces wave + 32, + 48, + 64 -> weight rows r0, r0 + 128, r0 + 256 (the swizzle differs per piece)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int row = min(r0 + 128 * k, BN - 1);
+        woffk[k] = (unsigned)(row * p.ldw * (int)sizeof(T)) + stage_chunk_w(row, lane, FN) * 16;
+    }
+    auto stage = [&](int slot, int kt) {
+        unsigned char* st = smem + slot * STAGE + wave * 1024;
+        const size_t ko = (size_t)kt * (GEMM_BK * sizeof(T));
+        glds16(xb + ko, st);
+        glds16(xb + xstride + ko, st + 16 * 1024);
+        glds16(wb + woffk[0] + ko, st + 32 * 1024);
+        glds16(wb + woffk[1] + ko, st + 48 * 1024);
+        if (wave < NI - 64) glds16(wb + woffk[2] + ko, st + 64 * 1024);
+    };
+
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int xr = wm * TM + (lane & 15);
+        const int wr = wn * TN + w_frag_row(lane & 15, 0, FN);
+        xoff[kk] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
+        woff[kk] = XT_BYTES + tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+    }
+
+    stage(0, 0);
+    // (mean, rstd) of the tile's 256 token rows, merged from the producer GEMM's slot partials (imh_lnstats.h) beside tile 0's flight
+    if (tid < BM) {
+        const f32x2s mr = merge_row_stats(p.ln_stats, m0 + tid, p.ln_slots, p.K, p.ln_eps);
+        *(f32x2s*)(smem + 2 * STAGE + tid * 8) = mr;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if W16_TIMING
+    const unsigned long long ts_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int t = 0; t < nkt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces of tile t have landed (and its statistics row is written)
+        __builtin_amdgcn_s_barrier();                                    // ... everyone's; every wave is past its reads of tile t - 1
+        asm volatile("" ::: "memory");
+        if (t + 1 < nkt) stage((t + 1) & 1, t + 1);
+        const unsigned char* st = smem + (t & 1) * STAGE;
+        // 128 registers per wave: 80 accumulators leave room for the four token fragments of a k step and TWO weight fragments -- the weight
+        // fragment of column block j + 1 is read while the four MFMAs of block j issue; the fences keep hipcc from hoisting all nine reads of
+        // a k step (it then spills 92 registers)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 xf[FM], wf[2];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[i] = *(const v8*)(st + xoff[kk] + i * 16 * GEMM_ROW_BYTES);
+            wf[0] = *(const v8*)(st + woff[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if (j + 1 < FN) wf[(j + 1) & 1] = *(const v8*)(st + woff[kk] + (j + 1) * 4 * GEMM_ROW_BYTES);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = mfma16(wf[j & 1], xf[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#if W16_TIMING
+    const unsigned long long ts_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // ---- epilogue: y = rstd_m (acc - mean_m s_n) + c_n, then out[2k], out[2k + 1] = value * gelu(gate) per quad (GEGLU) -- fragment by
+    //      fragment (its four (s_n, c_n) pairs fetched once for the four rows), a row's ten outputs packed and stored as 16 + 4 bytes ----
+    const int nb = n0 + wn * TN + (lane >> 4) * (4 * FN);
+    const float* ex = (const float*)(smem + 2 * STAGE);
+    float mean[FM], rstd[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int r = wm * TM + i * 16 + (lane & 15);
+        mean[i] = ex[r * 2]; rstd[i] = ex[r * 2 + 1];
+    }
+    const bool geglu = p.flags & GF_GEGLU;
+    if (geglu) {
+        typename Pk2<T>::t outp[FM][FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + 4 * j), c4 = *(const f32x4*)(p.ln_c + nb + 4 * j);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float v[4], o[2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fma_nopk(rstd[i], fma_nopk(-mean[i], s4[e], acc[i][j][e]), c4[e]);      // (no bias: fold_ln puts it into c_n)
+                geglu_quads<4>(v, o);
+                outp[i][j][0] = from_f32<T>(o[0]);
+                outp[i][j][1] = from_f32<T>(o[1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * TM + i * 16 + (lane & 15);
+            T* y = (T*)p.Y + (size_t)m * p.ldy + (nb >> 1);
+            typedef typename Pk2<T>::t pk2;
+            struct alignas(4) Row { pk2 q[FN]; } row;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) row.q[j] = outp[i][j];
+            // 10 outputs = 20 B at a 4-B-aligned address (nb / 2 is a multiple of 10 elements): five 4-B pieces would be five store instructions;
+            // stv's 16 + 4 split needs the first piece 16-B aligned, which (nb / 2) * 2 B = 20 k B is not -- so: 4-B pieces, merged by the compiler where it can
+#pragma unroll
+            for (int j = 0; j < FN; ++j) *(pk2*)(y + 2 * j) = row.q[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * TM + i * 16 + (lane & 15);
+            float v[4 * FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + 4 * j), c4 = *(const f32x4*)(p.ln_c + nb + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = fma_nopk(rstd[i], fma_nopk(-mean[i], s4[e], acc[i][j][e]), c4[e]);
+            }
+            stv<T, 4 * FN>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+        }
+    }
+#if W16_TIMING
+    if (tid == 0 && p.pf_ptr && p.pf_bytes == 0xfeed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + 8 + (size_t)blockIdx.x * 4;
+        dbg[0] = ts_entry; dbg[1] = ts_loop0; dbg[2] = ts_loop1; dbg[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#else
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 1024);
+#endif
+}
+
+template <typename T>
+static int launch_w16(const GemmParams& p, hipStream_t stream) {
+    GemmParams q = p;
+    int tiles;
+    xcd_partition(q, 256, 320, &tiles);
+    const int smem = 2 * (256 + 320) * GEMM_ROW_BYTES + 256 * 8;
+    auto kern = gemm_w16_kernel<T>;
+    static DynLdsOnce lds_once;
+    lds_once.ensure((const void*)kern, smem);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), smem, stream, q);
+    return check_launch("gemm_w16_kernel");
+}
+
+// variant 26256 x 320
+int gemm_w16_launch(const GemmParams& p, int dtype, hipStream_t stream) {
+    if (!(p.flags & GF_LN_ROW) || (p.flags & ~(GF_LN_ROW | GF_GEGLU)) || !p.ln_stats || p.bias || p.residual || p.rowadd || p.splits > 1 || p.X2 || p.Yt ||
+        p.ln_stats_out || p.gn_out || p.M % 256 || p.N % 320 || (p.ldy & 1) || (p.ldx & 7) || (p.ldw & 7)) {
+        set_error("gemm 26256 x 320 (sixteen-wave 256 x 320 tile): row-form folded LayerNorm with handed-over statistics (+ GEGLU) only, whole tiles "
+                  "(M %% 256, N %% 320), no bias (fold_ln folds it into ln_c) / residual / row-add / split-K / statistics epilogue (M=%d N=%d flags=%d)", p.M, p.N, p.flags);
+        return IMH_ERR_ARG;
+    }
+    if (dtype == IMH_DT_BF16) return launch_w16<bf16_t>(p, stream);
+    if (dtype == IMH_DT_F16) return launch_w16<f16_t>(p, stream);
+    set_error("gemm_w16: unknown dtype %d", dtype);
+    return IMH_ERR_DTYPE;
+}
+
+}  // namespace imh

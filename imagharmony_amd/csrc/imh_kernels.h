@@ -61,6 +61,7 @@ int gemm_stats_slot_width(int bm, int bn);       // channels per ln_stats_out sl
 int gemm_gn_block_rows(int bm, int bn);         // pixels per gn_out block of a tile variant (one wave's rows), 0 = no GroupNorm epilogue
 int gemm_launch(GemmParams p, int dtype, int conv, int bm, int bn, hipStream_t stream);
 int gemm_dual_launch(GemmParams a, GemmParams b, int dtype, int bm, int bn, hipStream_t stream);
+int gemm_w16_launch(const GemmParams& p, int dtype, hipStream_t stream);      // variant 26256 x 320 (gemm_w16.hip)
 
 struct AttnParams {
     const void* Q;    // [B, Lq, ldq] (+ head*64 columns)

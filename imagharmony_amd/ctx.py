@@ -32,6 +32,9 @@ def _read_tuning():
     try:
         with open(_TUNING_PATH) as f:
             raw = json.load(f)
+        extra = os.environ.get("IMH_TUNING_OVERRIDE")      # A/B aid: a JSON object of entries laid over tuning.json, e.g. '{"2048,10240,1280,0,1": [23256, 160, 1]}'
+        if extra:
+            raw.update(json.loads(extra))
         return {tuple(int(v) for v in k.split(",")): tuple(cfg) for k, cfg in raw.items()}
     except (OSError, ValueError):
         return {}
@@ -195,12 +198,15 @@ class Ctx:
     # variant codes (include/imh.h): what each family can do, so that a tuning-table entry (keyed by shape only) is never
     # handed a launch it rejects
     _WS = (1464, 2464, 24128, 23256, 22128)   # wave-specialised (gemm_ring.hip); 22128: two workgroups per CU
+    _W16 = (26256,)                           # sixteen-wave 256 x 320 (gemm_w16.hip): row-form folded LayerNorm (+ GEGLU) launches only
     _PP = (8256, 9128, 9256)                  # ping-pong (gemm_pp.hip)
     _HALO = (7128, 7564, 7328, 7428, 7256, 7356)   # LDS-halo conv3x3, stride 1 (7328 / 7428: weight rings; 7256 / 7356: 16 x 16 patch)
 
     @classmethod
     def _variant_ok(cls, bm, sp, flags, conv, stride, ln_pre):
         plain = bm <= 128
+        if bm in cls._W16:
+            return not conv and sp == 1 and bool(flags & L.GF_LN_ROW) and not flags & ~(L.GF_LN_ROW | L.GF_GEGLU) and bool(ln_pre)
         if bm in cls._HALO:
             return bool(conv) and stride == 1 and not flags & (L.GF_LN_ROW | L.GF_LN_COL | L.GF_VT_PERM)
         if flags & (L.GF_VT_PERM | L.GF_LN_COL):

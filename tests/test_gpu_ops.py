@@ -711,6 +711,40 @@ def test_gemm_folded_layernorm(L, dtype, cfg, shape):
         ctx.gemm(x, wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5), cfg=(64, 64, 2))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,slots", [((256, 320, 64), 1), ((512, 640, 1280), 16), ((2048, 10240, 1280), 16), ((768, 960, 640), 8)])
+def test_gemm_sixteen_wave_256x320_tile(L, dtype, shape, slots):
+    """Round 6, csrc/gemm_w16.hip (variant 26256 x 320; tuning.json takes it for the ff.net.0 launches): row-form folded LayerNorm with
+    handed-over statistics, plain and + GEGLU, (a) against F.layer_norm + matmul (+ GEGLU) in fp32, (b) BIT-identical to the
+    wave-specialised 256 x 160 kernel it replaces (same operands, same order of operations per output element), (c) bitwise repeatable;
+    and the launch refuses what it does not implement (a bias, a residual, ragged tiles) with a status code."""
+    from conftest import ref_row_stats
+    from imagharmony_amd.attention_processor import fold_ln
+    ctx = ctx_for(dtype)
+    M, N, K = shape
+    x = (rnd(M, K, dtype=dtype, seed=1) * 1.5 + 3.0).contiguous()
+    w = rnd(N, K, dtype=torch.float32, seed=2, scale=K ** -0.5)
+    norm = torch.nn.LayerNorm(K, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3)))
+        norm.bias.copy_(0.3 * torch.randn(K, generator=torch.Generator().manual_seed(4)))
+    ref = (F.layer_norm(x.float().cpu(), (K,), norm.weight, norm.bias, 1e-5) @ w.cpu().t()).to(DEV)
+    wg, s, c = fold_ln(w, norm, ctx)
+    st = (ref_row_stats(x.float(), slots).to(DEV), slots) if slots > 1 else ctx.row_stats(x)
+    for flags, want, what in ((L.GF_LN_ROW, ref, "LN"), (L.GF_LN_ROW | L.GF_GEGLU, geglu_ref(ref), "LN + GEGLU")):
+        y = ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))
+        assert_close(y, want, dtype, f"sixteen-wave 256 x 320, {what} {shape}", k=8.0)
+        assert torch.equal(y, ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(23256, 160, 1))), f"{what}: differs from the 256 x 160 kernel"
+        assert torch.equal(y, ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))), f"{what}: not repeatable"
+    b = rnd(N, dtype=dtype, seed=5)
+    with pytest.raises(L.ImhError, match="26256"):
+        ctx.gemm(x, wg, bias=b, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))
+    with pytest.raises(L.ImhError, match="26256"):
+        ctx.gemm(x[:M - 64], wg, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, (st[0][:M - 64], st[1])), cfg=(26256, 320, 1))
+    with pytest.raises(L.ImhError):
+        ctx.gemm(x, wg, cfg=(26256, 320, 1))                      # no folded LayerNorm: not this variant's launch
+
+
 def test_gemm_folded_layernorm_zero_variance_rows(L):
     """constant rows (variance 0): rstd = 1/sqrt(eps), finite output equal to the bias term W beta"""
     from imagharmony_amd.attention_processor import fold_ln

@@ -29,6 +29,10 @@ from tools.sweep import DEV, build_unet, record                        # noqa: E
 CONFIGS = collections.OrderedDict([
     # round 4 (the round-2 / round-3 sessions' configurations are in git history; their results in profiles/r03_forward_ab_*.json)
     ("base", dict()),
+    # round 6: ff.net.0 on the sixteen-wave 256 x 320 tile (gemm_w16.hip) -- one round of 256 workgroups at UNet batch 2
+    ("geglu_w16", dict(tuning={"2048,10240,1280,0,1": [26256, 320, 1], "8192,5120,640,0,1": [26256, 320, 1],
+                               "8192,10240,1280,0,1": [26256, 320, 1], "32768,5120,640,0,1": [26256, 320, 1]})),
+    ("geglu_w16_1280", dict(tuning={"2048,10240,1280,0,1": [26256, 320, 1], "8192,10240,1280,0,1": [26256, 320, 1]})),
     # self-attention key loop (imh_debug_set key 4): 1 in-order, 3 software-pipelined + deferred maximum (the round-3 default),
     # 5 key-split workgroups (round 4)
     ("attn1", dict(attn=1)),
