@@ -622,7 +622,7 @@ def main():
         # runs of this same command, FETCH_SIZE x2 for gfx950): measured offline, committed under profiles/
         traffic, traffic_src = None, None
         try:
-            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
+            pj = next(q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
                                                                           "r01_pmc_hbm_traffic_final.json")) if os.path.exists(q))
             traffic = json.load(open(pj))["gemm_family"]["hbm_bytes_per_launch"]
             traffic_src = f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command with --denoise-steps 4)"

@@ -779,6 +779,8 @@ class Ctx:
             out.append((t.data_ptr(), min(t.numel() * t.element_size(), 0xFFFFFFF0)))
         return out
 
+    PF_CHUNK, PF_CAP_ONLY, PF_BACK = 0, False, 3
+
     def finalize_prefetch(self):
         """Give every recorded launch the weights of the launch that follows it (tail_prefetch in the kernels):
         a cold weight matrix goes to the nearest earlier op (up to 3 back) whose prefetch slot is still free."""
@@ -798,20 +800,32 @@ class Ctx:
             return True
 
         taken = set()
+        # PF_CHUNK (bytes; A/B, tools/forward_ab.py `pf_chunk`): a weight matrix larger than this is handed out in pieces -- the first to the
+        # nearest earlier launch with a free slot, the next to the one before it, ... (up to PF_BACK launches back); PF_CAP: pieces beyond
+        # the first are dropped instead (what is not prefetched is read cold)
+        chunk, cap_only, back = self.PF_CHUNK, self.PF_CAP_ONLY, self.PF_BACK
         for j, (kind, args, cold) in enumerate(self._ops):
             for (ptr, nb) in cold:
+                pieces = [(ptr, nb)]
+                if chunk and nb > chunk:
+                    pieces = [(ptr + o, min(chunk, nb - o)) for o in range(0, nb, chunk)]
+                    if cap_only:
+                        pieces = pieces[:1]
                 # nearest earlier launch with a free slot (measured better than handing big matrices to a longer,
                 # earlier kernel: 27.0 vs 27.3 ms per forward)
-                for i in range(j - 1, max(j - 4, -1), -1):
-                    if i in taken or not carries(i):
-                        continue
+                i = j - 1
+                for (pp, pn) in pieces:
+                    while i > max(j - 1 - back, -1) and (i in taken or not carries(i)):
+                        i -= 1
+                    if i <= max(j - 1 - back, -1):
+                        break
                     a = self._ops[i][1]
                     tgt = a[0] if self._ops[i][0] == L.OP_GEMM_DUAL else a
-                    tgt.pf_ptr, tgt.pf_bytes = ptr, nb
+                    tgt.pf_ptr, tgt.pf_bytes = pp, pn
                     ref = C.cast(a, C.c_void_p) if self._ops[i][0] == L.OP_GEMM_DUAL else C.byref(a)
                     L.check(self.lib.imh_plan_update(self.plan, i, ref), "imh_plan_update")
                     taken.add(i)
-                    break
+                    i -= 1
         return len(taken)
 
     # ------------------------------------------------------------------ plans

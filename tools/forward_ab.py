@@ -29,6 +29,10 @@ from tools.sweep import DEV, build_unet, record                        # noqa: E
 CONFIGS = collections.OrderedDict([
     # round 4 (the round-2 / round-3 sessions' configurations are in git history; their results in profiles/r03_forward_ab_*.json)
     ("base", dict()),
+    # round 6: where does the tail prefetch of the 26-MB ff.net.0 weight go?  cap = only the first N MB prefetched (by the launch before); chunk = N-MB pieces
+    # handed to the launches before, nearest first
+    ("pf_cap8", dict(pf_chunk=8 << 20, pf_cap=True)), ("pf_cap4", dict(pf_chunk=4 << 20, pf_cap=True)), ("pf_off", dict(pf_chunk=4096, pf_cap=True)),
+    ("pf_chunk8", dict(pf_chunk=8 << 20, pf_back=4)), ("pf_chunk13", dict(pf_chunk=13 << 20, pf_back=3)), ("pf_chunk4", dict(pf_chunk=4 << 20, pf_back=7)),
     # round 6: ff.net.0 on the sixteen-wave 256 x 320 tile (gemm_w16.hip) -- one round of 256 workgroups at UNet batch 2
     ("geglu_w16", dict(tuning={"2048,10240,1280,0,1": [26256, 320, 1], "8192,5120,640,0,1": [26256, 320, 1],
                                "8192,10240,1280,0,1": [26256, 320, 1], "32768,5120,640,0,1": [26256, 320, 1]})),
@@ -127,12 +131,15 @@ def main():
         lib.imh_debug_set(2, int(c.get("xcd", 0)))
         lib.imh_debug_set(5, int(c.get("halo", 0)))
         lib.imh_debug_set(6, int(c.get("ws_early", 1)))
+        from imagharmony_amd.ctx import Ctx as _Ctx
+        _Ctx.PF_CHUNK, _Ctx.PF_CAP_ONLY, _Ctx.PF_BACK = int(c.get("pf_chunk", 0)), bool(c.get("pf_cap", False)), int(c.get("pf_back", 3))
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
         rec, out, st = record(u, dtype, 128, S=a.stacked, tuning=tun, cells=int(c.get("cells", 0)))
         rec.run()
         torch.cuda.synchronize()
+        _Ctx.PF_CHUNK, _Ctx.PF_CAP_ONLY, _Ctx.PF_BACK = 0, False, 3
         plans[n] = (rec, c)
         outs[n] = out.float().clone()
     ref = outs[names[0]]

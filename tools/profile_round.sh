@@ -26,5 +26,8 @@ timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFM
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d $out/${tag}_x2$shp -o s -- python tools/pmc_ipattn.py $shp > /dev/null 2>&1; echo "ipattn $shp sq2 rc=$?"
 python tools/pmc_sq_summary.py $(find $out/${tag}_x1$shp -name "*results.db" | head -1) $(find $out/${tag}_x2$shp -name "*results.db" | head -1) | sed "s/^# SQ counters per launch.*/# SQ counters per launch of the north-star IP-attention call, $shp (tools\/pmc_ipattn.py: xattn_kernel + to_out gemm_ws 64x160)/" > $out/${tag}_pmc_sq_ipattn_$shp.md
 done
+# the headline configuration end to end against the fp32 CPU oracle (~5 min of host time), recorded with every other measured parity number
+IMH_SLOW=1 timeout 1500 python -m pytest tests/test_gpu_parity_fullsize.py -x -q -m gpu -k "configs1_1024" > $out/${tag}_trajectory30.log 2>&1; echo "trajectory rc=$?"
+cp $out/parity_measured.json $out/${tag}_parity.json 2>/dev/null
 rm -rf $out/${tag}_kt $out/${tag}_pf $out/${tag}_pw $out/${tag}_s1 $out/${tag}_s2 $out/${tag}_x1cfg2 $out/${tag}_x2cfg2 $out/${tag}_x1cfg4 $out/${tag}_x2cfg4
 ls -la $out | grep ${tag}_
