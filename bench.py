@@ -323,8 +323,18 @@ def box_calibration(device, dtype, reps=20):
         us = e0.elapsed_time(e1) * 1e3 / reps
         best = us if best is None else min(best, us)
     fl = 2.0 * M * N * K
+    # ... and the clock / power the part sustains under this launch alone (~2 s of back-to-back replays, sampled from the host): a dense MFMA
+    # kernel is power-limited well below 2.4 GHz, so its fraction of the peak AT THAT CLOCK is what says how busy the matrix pipes are
+    clk = ClockSampler(period=0.25)
+    t_end = time.perf_counter() + 2.0
+    while time.perf_counter() < t_end:
+        rec.run()
+        torch.cuda.synchronize(device)
+    clocks = clk.stop()
+    tf = fl / (best * 1e-6) / 1e12
     return {"launch": "imh::gemm_ws_kernel 256x160 (variant 23256), 8192 x 5120 x 2560, bf16 random operands", "us": best,
-            "tflops": fl / (best * 1e-6) / 1e12, "reference_us": 186.0,
+            "tflops": tf, "reference_us": 186.0, "clocks_under_this_launch": clocks,
+            "frac_of_peak_at_sampled_clock": (tf / clocks["mfma_peak_at_this_clock_tflops"]) if clocks else None,
             "note": "reference_us = the same launch on the round-3 profile box (profiles/r03_pmc_sq_gemm_attn.md); us / reference_us "
                     "scales this box against it"}
 

@@ -244,6 +244,7 @@ int imh_debug_set(int key, int value) {
     if (key == 3) { g_xattn_mode = value; return IMH_OK; }
     if (key == 4) { g_attn_mode = value; return IMH_OK; }
     if (key == 5) { g_halo_mode = value; return IMH_OK; }
+    if (key == 7) { g_w16_pf = value; return IMH_OK; }        // sixteen-wave ff.net.0 tile: 1 (default) = the next launch's weights prefetched inside the K loop, 0 = behind the epilogue
     if (key == 6) { g_ws_early = value; return IMH_OK; }      // 0: the residual rows of the wave-specialised launches fetched after the K loop (A/B)
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;

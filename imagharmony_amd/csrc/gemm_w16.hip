@@ -20,6 +20,8 @@
 
 namespace imh {
 
+int g_w16_pf = 1;        // imh_debug_set key 7: 1 (default) = the next launch's weights prefetched inside the K loop, 0 = behind the epilogue (A/B)
+
 #ifndef W16_TIMING
 #define W16_TIMING 0
 #endif
@@ -94,11 +96,34 @@ __global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
 #if W16_TIMING
     const unsigned long long ts_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // The next launch's weights (ff.net.2: 13 MB) -- this kernel has no producer waves whose tail prefetch would run beside the epilogue, and a
+    // prefetch behind the epilogue's stores cost the launch 3.3 us (profiles/r06_forward_ab_prefetch.log, `pf_off`).  So this workgroup's slice travels INSIDE
+    // the K loop instead (g_w16_pf, imh_debug_set key 7; 0 = the tail form.  ff.net.0 67.6 -> 64.3 us in the forward, bit-identical; 603.1 ->
+    // 600.3 ms per denoise over alternating bench.py processes: profiles/r06_forward_ab_w16_pf_loop.log, r06_bench_ab_w16_pf_loop.txt): one LDS-DMA piece (1 KB, landing in a scratch KB of LDS nobody
+    // reads) per wave behind every PFS-th tile's operand pieces; it is the youngest entry of the wave's queue, so the next tile's wait leaves
+    // exactly it in flight (vmcnt(1)) and the wait after that retires it with the operands it precedes.
+    const bool pf_loop = p.early_res == 2 && p.pf_ptr != nullptr;       // (early_res carries the mode: the launcher sets 2)
+    const unsigned pf_per = pf_loop ? ((((p.pf_bytes + gridDim.x - 1) / gridDim.x) + 1023u) & ~1023u) : 0u;     // this workgroup's slice, whole KB
+    const unsigned pf_s0 = blockIdx.x * pf_per;
+    const int pf_n = pf_loop ? (int)((min(p.pf_bytes, pf_s0 + pf_per) > pf_s0 ? min(p.pf_bytes, pf_s0 + pf_per) - pf_s0 : 0u) >> 10) : 0;     // KB pieces
+    const int pf_rounds = (pf_n + 15) >> 4;                             // tiles that carry a piece per wave
+    const int PFS = pf_rounds > 0 ? max(1, (nkt - 1) / pf_rounds) : 1;
+    unsigned char* const pf_lds = smem + 2 * STAGE + 256 * 8;
+    bool pf_in_flight = false;
     for (int t = 0; t < nkt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces of tile t have landed (and its statistics row is written)
+        if (pf_in_flight) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");     // tile t has landed; the prefetch piece issued behind it stays in flight
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  // this wave's pieces of tile t have landed (and its statistics row is written)
         __builtin_amdgcn_s_barrier();                                    // ... everyone's; every wave is past its reads of tile t - 1
         asm volatile("" ::: "memory");
         if (t + 1 < nkt) stage((t + 1) & 1, t + 1);
+        pf_in_flight = false;
+        if (pf_loop && t + 1 < nkt && t % PFS == 0) {
+            const int q = (t / PFS) * 16 + wave;
+            if (q < pf_n) {                                              // (wave-uniform)
+                glds16((const unsigned char*)p.pf_ptr + pf_s0 + (size_t)q * 1024 + lane * 16, pf_lds);
+                pf_in_flight = true;
+            }
+        }
         const unsigned char* st = smem + (t & 1) * STAGE;
         // 128 registers per wave: 80 accumulators leave room for the four token fragments of a k step and TWO weight fragments -- the weight
         // fragment of column block j + 1 is read while the four MFMAs of block j issue; the fences keep hipcc from hoisting all nine reads of
@@ -184,16 +209,17 @@ __global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
         dbg[0] = ts_entry; dbg[1] = ts_loop0; dbg[2] = ts_loop1; dbg[3] = __builtin_amdgcn_s_memrealtime();
     }
 #else
-    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 1024);
+    if (!pf_loop) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 1024);
 #endif
 }
 
 template <typename T>
 static int launch_w16(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
+    q.early_res = g_w16_pf ? 2 : 0;
     int tiles;
     xcd_partition(q, 256, 320, &tiles);
-    const int smem = 2 * (256 + 320) * GEMM_ROW_BYTES + 256 * 8;
+    const int smem = 2 * (256 + 320) * GEMM_ROW_BYTES + 256 * 8 + 1024;      // + the prefetch pieces' scratch KB
     auto kern = gemm_w16_kernel<T>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, smem);

@@ -780,6 +780,14 @@ class Ctx:
         return out
 
     PF_CHUNK, PF_CAP_ONLY, PF_BACK = 0, False, 3
+    # Round 6: a weight matrix larger than PF_BIG is NOT handed to the launch before it (only its first PF_BIG_CAP bytes, 0 = none).  The one
+    # such matrix of the UNet is ff.net.0's [10240, 1280] (26 MB): prefetching it at the tail of the cross-attention's to_out cost that launch
+    # 3.8 us (19.4 vs 15.7 us -- the "4 us slower behind the fused cross-attention than behind the self-attention" of round 5's trace) and
+    # bought ff.net.0 nothing: its K loops hide their own weight stream (62.2 vs 62.1 us).  -0.28 ms per forward, 559.5 / 561.7 -> 551.6 /
+    # 551.3 ms per 30-step denoise in alternating processes (profiles/r06_forward_ab_prefetch_big.json, r06_bench_ab_prefetch_big.txt).
+    # Conv weights of that size keep their prefetch: the LDS-halo kernels' two-slot weight rings do not hide a cold stream (8192 x 640 x 17280:
+    # 202.9 -> 233.8 us without).  IMH_PF_BIG=0 restores the round-5 behaviour (A/B).
+    PF_BIG, PF_BIG_CAP = int(os.environ.get("IMH_PF_BIG", str(14 << 20))), int(os.environ.get("IMH_PF_BIG_CAP", "0"))
 
     def finalize_prefetch(self):
         """Give every recorded launch the weights of the launch that follows it (tail_prefetch in the kernels):
@@ -807,7 +815,10 @@ class Ctx:
         for j, (kind, args, cold) in enumerate(self._ops):
             for (ptr, nb) in cold:
                 pieces = [(ptr, nb)]
-                if chunk and nb > chunk:
+                is_conv = kind == L.OP_GEMM and bool(getattr(args, "conv", 0))
+                if self.PF_BIG and nb > self.PF_BIG and not is_conv:      # a Linear weight this large: only its first PF_BIG_CAP bytes (0 = none) are prefetched
+                    pieces = [(ptr, self.PF_BIG_CAP)] if self.PF_BIG_CAP > 0 else []
+                elif chunk and nb > chunk:
                     pieces = [(ptr + o, min(chunk, nb - o)) for o in range(0, nb, chunk)]
                     if cap_only:
                         pieces = pieces[:1]

@@ -162,6 +162,10 @@ def load():
         fn.argtypes = args
     if lib.imh_abi_version() != ABI_VERSION:
         raise ImhError("libimh_hip.so ABI version mismatch")
+    # measurement knob (tools/, alternating bench.py processes): IMH_DEBUG_SET="key=value,..." -> imh_debug_set at load
+    for kv in filter(None, os.environ.get("IMH_DEBUG_SET", "").split(",")):
+        k, v = kv.split("=")
+        lib.imh_debug_set(int(k), int(v))
     _lib = lib
     return lib
 

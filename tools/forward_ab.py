@@ -26,12 +26,17 @@ from imagharmony_amd import attention_processor as AP                 # noqa: E4
 from imagharmony_amd.ctx import _load_tuning                           # noqa: E402
 from tools.sweep import DEV, build_unet, record                        # noqa: E402
 
+from imagharmony_amd.ctx import Ctx as _CtxD                          # noqa: E402
+_PF_DEFAULT = (_CtxD.PF_BIG, _CtxD.PF_BIG_CAP)
 CONFIGS = collections.OrderedDict([
     # round 4 (the round-2 / round-3 sessions' configurations are in git history; their results in profiles/r03_forward_ab_*.json)
     ("base", dict()),
     # round 6: where does the tail prefetch of the 26-MB ff.net.0 weight go?  cap = only the first N MB prefetched (by the launch before); chunk = N-MB pieces
     # handed to the launches before, nearest first
     ("pf_cap8", dict(pf_chunk=8 << 20, pf_cap=True)), ("pf_cap4", dict(pf_chunk=4 << 20, pf_cap=True)), ("pf_off", dict(pf_chunk=4096, pf_cap=True)),
+    ("w16_pf_tail", dict(w16_pf=0)),        # round 6: ff.net.0 prefetching ff.net.2 behind its epilogue (the in-loop form is the default)
+    ("pf_big0", dict(pf_big=14 << 20, pf_big_cap=0)), ("pf_big2", dict(pf_big=14 << 20, pf_big_cap=2 << 20)), ("pf_big4", dict(pf_big=14 << 20, pf_big_cap=4 << 20)),
+    ("pf_big8", dict(pf_big=14 << 20, pf_big_cap=8 << 20)), ("pf_big13", dict(pf_big=14 << 20, pf_big_cap=13 << 20)),
     ("pf_chunk8", dict(pf_chunk=8 << 20, pf_back=4)), ("pf_chunk13", dict(pf_chunk=13 << 20, pf_back=3)), ("pf_chunk4", dict(pf_chunk=4 << 20, pf_back=7)),
     # round 6: ff.net.0 on the sixteen-wave 256 x 320 tile (gemm_w16.hip) -- one round of 256 workgroups at UNet batch 2
     ("geglu_w16", dict(tuning={"2048,10240,1280,0,1": [26256, 320, 1], "8192,5120,640,0,1": [26256, 320, 1],
@@ -131,8 +136,10 @@ def main():
         lib.imh_debug_set(2, int(c.get("xcd", 0)))
         lib.imh_debug_set(5, int(c.get("halo", 0)))
         lib.imh_debug_set(6, int(c.get("ws_early", 1)))
+        lib.imh_debug_set(7, int(c.get("w16_pf", 1)))
         from imagharmony_amd.ctx import Ctx as _Ctx
         _Ctx.PF_CHUNK, _Ctx.PF_CAP_ONLY, _Ctx.PF_BACK = int(c.get("pf_chunk", 0)), bool(c.get("pf_cap", False)), int(c.get("pf_back", 3))
+        _Ctx.PF_BIG, _Ctx.PF_BIG_CAP = int(c.get("pf_big", _PF_DEFAULT[0])), int(c.get("pf_big_cap", _PF_DEFAULT[1]))
         tun = dict(_load_tuning())
         for k, v in (c.get("tuning") or {}).items():
             tun[tuple(int(x) for x in k.split(","))] = tuple(v)
@@ -140,6 +147,7 @@ def main():
         rec.run()
         torch.cuda.synchronize()
         _Ctx.PF_CHUNK, _Ctx.PF_CAP_ONLY, _Ctx.PF_BACK = 0, False, 3
+        _Ctx.PF_BIG, _Ctx.PF_BIG_CAP = _PF_DEFAULT
         plans[n] = (rec, c)
         outs[n] = out.float().clone()
     ref = outs[names[0]]
@@ -153,6 +161,7 @@ def main():
             lib.imh_debug_set(2, int(c.get("xcd", 0)))
             lib.imh_debug_set(5, int(c.get("halo", 0)))
             lib.imh_debug_set(6, int(c.get("ws_early", 1)))
+            lib.imh_debug_set(7, int(c.get("w16_pf", 1)))
             ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
@@ -168,6 +177,7 @@ def main():
     lib.imh_debug_set(2, 0)
     lib.imh_debug_set(5, 0)
     lib.imh_debug_set(6, 1)
+    lib.imh_debug_set(7, 1)
     out = {}
     for n in names:
         rec, c = plans[n]
