@@ -28,6 +28,7 @@
 #include "imh_kernels.h"
 #include "imh_gemm_epilogue.h"
 #include "imh_lnstats.h"
+#include "imh_halo_norm.h"
 
 namespace imh {
 
@@ -149,28 +150,28 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
     // GroupNorm (+ SiLU) of the staged chunk, in place, by the wave that staged it (its own DMA pieces: its own vmcnt wait covers them);
     // every piece of a lane holds the same logical 16-B chunk (h & 7 == (lane >> 3) & 7 whatever the piece), i.e. the same 8 channels
     const int gch = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-    // pieces [q0, q1) of the wave (one piece = 8 halo pixels x 64 channels; ~70 VALU instructions per lane)
-    auto norm_halo = [&](int buf, int ct, int q0, int q1) {
+    // pieces [q0, q1) of the wave (one piece = 8 halo pixels x 64 channels), q1 - q0 <= NMAX per call: imh_halo_norm.h
+    HaloNorm<T> hn;
+    unsigned realmask = 0;                               // bit q: this lane's pixel of piece q is inside the image
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) realmask |= (hstep[q] != 0 ? 1u : 0u) << q;
+    auto norm_halo_n = [&](int buf, int ct, int q0, int q1, auto NMAX) {
+        constexpr int N = decltype(NMAX)::value;
         unsigned char* d = halo0 + buf * CH_HALO_BYTES;
-        float sc[8], sh[8];
-        const f32x4* tb = (const f32x4*)(gtab + (ct * GEMM_BK + gch) * 2);
+        hn.load(gtab, ct, gch);
+        unsigned char* addr[N];
+        bool valid[N], real[N];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const f32x4 v = tb[e]; sc[2 * e] = v[0]; sh[2 * e] = v[1]; sc[2 * e + 1] = v[2]; sh[2 * e + 1] = v[3]; }
-#pragma unroll
-        for (int q = 0; q < HQ; ++q) {
-            if (q >= q0 && q < q1 && q * NSTG + sw < HPIECES) {
-                v8* a = (v8*)(d + (q * NSTG + sw) * 8 * GEMM_ROW_BYTES + lane * 16);
-                const v8 t = *a;
-                v8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f = __builtin_fmaf(to_f32(t[e]), sc[e], sh[e]);
-                    if (p.gn_silu) f = silu_f(f);
-                    o[e] = from_f32<T>(f);
-                }
-                if (hstep[q] != 0) *a = o;                  // padding pixels stay zero: the conv pads the normalised tensor
-            }
+        for (int k = 0; k < N; ++k) {
+            const int q = q0 + k;
+            valid[k] = q < q1 && q < HQ && q * NSTG + sw < HPIECES;
+            real[k] = (realmask >> q) & 1u;
+            addr[k] = d + (q * NSTG + sw) * 8 * GEMM_ROW_BYTES + lane * 16;
         }
+        hn.template run<N>(addr, valid, real, p.gn_silu != 0);
+    };
+    auto norm_halo = [&](int buf, int ct, int q0, int q1) {      // any range, in groups of two
+        for (int q = q0; q < q1; q += 2) norm_halo_n(buf, ct, q, min(q + 2, q1), std::integral_constant<int, 2>{});
     };
     // ---- weight staging: WPIECES pieces of 8 rows per step (tap-major); this wave takes pieces wave + 8 q ----
     const unsigned char* wsrc[WQ];
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                         // weight step `step` has landed.  Younger loads of this wave that may stay in flight: the weight steps behind it
                         // (at most S - 2) and the next chunk's halo if it was issued inside that window (at tap 0, behind that step's weights)
                         const int ahead = min(S - 2, nsteps - 1 - step);
-                        wait_vmcnt_dyn(ahead * nW + ((tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0));
+                        wait_vmcnt_of<(S - 2) * WQ, (S - 2) * (WQ - 1), (S - 2) * WQ + HQ, (S - 2) * WQ + HQ - 1, (S - 2) * (WQ - 1) + HQ, (S - 2) * (WQ - 1) + HQ - 1>(
+                            ahead * nW + ((tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0));
                     }
                     CH_TICK(0);
                     __builtin_amdgcn_s_barrier();                        // ... before the step that may read them; the halo buffer
@@ -287,10 +289,10 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                         if (tap == 0) stage_halo((ct + 1) & 1, ct + 1);
                         if constexpr (TPS == 1) {
                             // two steps of flight; behind the halo in this wave's queue: the weights issued at taps 1 and 2
-                            if (tap == 2) wait_vmcnt_dyn(staged(step - 1) + staged(step));
+                            if (tap == 2) wait_vmcnt_of<0, 2 * WQ, 2 * (WQ - 1)>(staged(step - 1) + staged(step));
                             if (gn && tap >= 2) norm_halo((ct + 1) & 1, ct + 1, (tap - 2) * PPT, (tap - 1) * PPT);
                         } else {                             // three long steps per chunk: issue / first half / second half
-                            if (tap == 1) wait_vmcnt_dyn(staged(step));
+                            if (tap == 1) wait_vmcnt_of<0, WQ, WQ - 1>(staged(step));
                             if (gn && tap >= 1) norm_halo((ct + 1) & 1, ct + 1, (tap - 1) * ((HQ + 1) / 2), tap * ((HQ + 1) / 2));
                         }
                     }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
             if constexpr (!SVC) {
                 const int ahead = min(S - 2, nsteps - 1 - step);
                 const int halo_in_window = (HWV == 0 && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0;
-                wait_vmcnt_dyn(ahead * nW + halo_in_window);
+                wait_vmcnt_of<(S - 2) * WQ, (S - 2) * (WQ - 1), (S - 2) * WQ + HQ, (S - 2) * (WQ - 1) + HQ>(ahead * nW + halo_in_window);
             }
             CH_TICK(0);
             __builtin_amdgcn_s_barrier();                            // ... everyone's; the previous step is fully consumed
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
 // couts per workgroup, wave tile 64 pixels x 80 couts like the wave-specialised GEMM's consumers: per MFMA 0.45 fragment reads
 // instead of 0.6 and 24.6 KB instead of 42.5 KB of operands per step for the 320-channel convolutions at the 128 x 128 latent)
 // with a 2- / 3-slot weight ring
+int conv_hws_launch(const GemmParams& p, int dtype, int ph, int tiles_x, int tiles_y, int tiles_n, int B, int lds_tab, hipStream_t stream);     // conv_hws.hip
 int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t stream) {
     const int ph = bm == 7564 ? 4 : ((bm == 7256 || bm == 7356) ? 16 : 8);
     // bn = 80: k halves per wave pair, three taps per step, service waves -- 7128 x 80: 8 x 16 patch, 3-slot ring; 7256 x 80: 16 x 16 patch
@@ -489,6 +492,10 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     // the four halo waves for every launch (round 5: the un-fused launches gain too -- upsample 8192 x 1280 x 11520 258 -> 245 us,
     // profiles/r05_forward_ab_conv32_ks80.json `halo_w12`); g_halo_mode 1 = the eight-wave form (A/B)
     const bool hw4 = g_halo_mode != 1;
+    // round 6: the 16 x 16 / 8 x 16 patch x 160 couts forms run wave-specialised (conv_hws.hip: same geometry, bit-identical results);
+    // g_halo_mode 6 = the kernels below (A/B, the bit-identity test)
+    if (!ks && bn == 160 && (bm == 7128 || bm == 7256 || bm == 7356) && g_halo_mode == 0)
+        return conv_hws_launch(p, dtype, ph, tiles_x, tiles_y, tiles_n, B, gnf ? p.Cin * 8 : 0, stream);
 #define IMH_CH6(TT, FNV, FMV, SV, HV, KSV, SVCV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV, SVCV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
@@ -513,7 +520,7 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
 #else
-    if (!hw4 || g_halo_mode >= 3 || bm == 7564 || bm == 7328 || bm == 7428 || (ks && ph == 16))
+    if (!hw4 || (g_halo_mode >= 3 && g_halo_mode != 6) || bm == 7564 || bm == 7328 || bm == 7428 || (ks && ph == 16))
         return experimental_refused("this LDS-halo conv form (eight-wave / service-wave A-B modes, variants 7564 / 7328 / 7428 / 7256 x 80)");
 #define IMH_CH3(TT, FNV, FMV, SV) IMH_CH6(TT, FNV, FMV, SV, 4, false, false)
 #define IMH_CH(TT) do { \

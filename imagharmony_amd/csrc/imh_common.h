@@ -85,6 +85,17 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {
 #undef IMH_VMC
 }
 
+// ... and the same wait where n is one of a few compile-time candidates in the steady state: an if-chain of one to four scalar compares.
+// (The 32-way switch above lowers to a tree of ~6 dependent scalar branches through the structurizer's flow blocks: 230-400 cycles PER CALL,
+// measured as a constant "vmcnt" / "weight wait" segment in every per-step probe of the LDS-halo convs -- tools/hws_phase_probe.py,
+// profiles/r05_halo_phase_probe.txt.  Keep wait_vmcnt_dyn for prologues and the ragged ends of a ring.)
+template <int N0, int... Ns>
+__device__ __forceinline__ void wait_vmcnt_of(const int n) {
+    if (n == N0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
+    else if constexpr (sizeof...(Ns) > 0) wait_vmcnt_of<Ns...>(n);
+    else wait_vmcnt_dyn(n);
+}
+
 // a 256-B page of zeros: out-of-range tile rows / conv padding taps fetch from here, so
 // the main loops carry no bounds branches
 static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];   // one copy per translation unit

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void xattn_wide_kernel(const XAttnParams xp
         __builtin_amdgcn_s_barrier();
         for (int j = 0; j < NT; ++j) {
             if (j + XW_KVR - 1 < NT) issue_kv(j + XW_KVR - 1);          // into the slot of tile j - 1
-            wait_vmcnt_dyn(4 * max(0, min(XW_KVR - 2, NT - 2 - j)));    // tile j + 1 has landed
+            wait_vmcnt_of<4 * (XW_KVR - 2), 4, 0>(4 * max(0, min(XW_KVR - 2, NT - 2 - j)));    // tile j + 1 has landed
             __builtin_amdgcn_s_barrier();                   // ... and tile j has been read
         }
 #if !XA_TIMING

@@ -341,6 +341,64 @@ def test_conv_over_a_two_source_concat_with_fused_groupnorm(L, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(B=2, H=32, W=32, C1=320, C2=0, Cout=320, cfg=(7256, 160, 1)), dict(B=1, H=32, W=48, C1=320, C2=320, Cout=320, cfg=(7256, 160, 1)),
+                                  dict(B=2, H=16, W=32, C1=640, C2=0, Cout=640, cfg=(7128, 160, 1)), dict(B=1, H=16, W=16, C1=1280, C2=640, Cout=640, cfg=(7128, 160, 1)),
+                                  dict(B=1, H=13, W=19, C1=320, C2=320, Cout=200, cfg=(7356, 160, 1)), dict(B=2, H=20, W=12, C1=64, C2=0, Cout=160, cfg=(7128, 160, 1)),
+                                  dict(B=1, H=8, W=8, C1=64, C2=0, Cout=320, up=1, cfg=(7256, 160, 1))])
+def test_wave_specialised_halo_conv_is_bit_identical_to_the_lockstep_form(L, dtype, case):
+    """round 6: conv_hws.hip (consumer / producer waves, reads pipelined across the step barrier, the consumers fill the weight ring) against conv_halo.hip's kernels for the
+    same variant codes (imh_debug_set(5, 6)) -- same tiles, same accumulation order: the same bits, with and without the fused
+    GroupNorm + SiLU front end (table launch and in-kernel table), the two-source concat, bias + time-embedding row + residual, the
+    GroupNorm partials of the output, ragged patch grids and cout tiles, fused upsampling"""
+    from imagharmony_amd.ctx import GnSpec
+    ctx = ctx_for(dtype)
+    B, H, W, C1, C2, Cout, cfg, up = case["B"], case["H"], case["W"], case["C1"], case["C2"], case["Cout"], case["cfg"], case.get("up", 0)
+    Cin = C1 + C2
+    a = (rnd(B, H, W, C1, dtype=dtype, seed=1) * 1.2 + 0.3).contiguous()
+    b = (rnd(B, H, W, C2, dtype=dtype, seed=2) * 0.7 - 0.2).contiguous() if C2 else None
+    w = pack_conv(rnd(Cout, Cin, 3, 3, dtype=dtype, seed=3, scale=(9 * Cin) ** -0.5))
+    bias, temb = rnd(Cout, dtype=dtype, seed=4), rnd(B, Cout, dtype=dtype, seed=5)
+    Ho, Wo = H << up, W << up
+    res = rnd(B * Ho * Wo, Cout, dtype=dtype, seed=6)
+    gamma, beta = rnd(Cin, dtype=dtype, seed=11) * 0.2 + 1.0, rnd(Cin, dtype=dtype, seed=12) * 0.3
+    gn_ok = not up and Cin % G == 0 and C1 % 10 == 0 and C2 % 10 == 0
+    parts = ([ctx.gn_stats(a.view(B, H * W, C1))] + ([ctx.gn_stats(b.view(B, H * W, C2))] if C2 else [])) if gn_ok else None
+    tab = ctx.gn_table(parts if C2 else parts[0], gamma, beta, G, 1e-5, H * W) if gn_ok else None
+    spec = GnSpec(parts, gamma, beta, G, 1e-5) if gn_ok else None
+
+    def run():
+        outs = [ctx.conv3x3(a, w, bias=bias, up=up, rowadd=temb, residual=res, cfg=cfg, x2=b)]
+        outs.append(ctx.conv3x3(a, w, cfg=cfg, up=up, x2=b))
+        if gn_ok:
+            outs.append(ctx.conv3x3(a, w, bias=bias, cfg=cfg, gn=(tab, True), x2=b))
+            outs.append(ctx.conv3x3(a, w, bias=bias, rowadd=temb, cfg=cfg, gn=(spec, True), x2=b))
+            outs.append(ctx.conv3x3(a, w, bias=bias, cfg=cfg, gn=(tab, False), x2=b))
+            y, gs = ctx.conv3x3(a, w, bias=bias, cfg=cfg, gn=(spec, True), x2=b, gn_groups=G)
+            outs.append(y)
+            if gs is not None:
+                outs.append(gs.t)
+        torch.cuda.synchronize()
+        return outs
+    new = run()
+    for mode in (6,):           # conv_halo.hip's lock-step kernels
+        try:
+            ctx.lib.imh_debug_set(5, mode)
+            old = run()
+        finally:
+            ctx.lib.imh_debug_set(5, 0)
+        assert len(new) == len(old)
+        for i, (x, y) in enumerate(zip(new, old)):
+            assert torch.equal(x, y), f"output {i} of {case}: the default kernel and mode {mode} differ"
+    # ... and right (the first launch against torch)
+    xin = (torch.cat([a, b], -1) if C2 else a).float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    w4 = w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).float()
+    ref = F.conv2d(xin, w4, bias.float(), padding=1).permute(0, 2, 3, 1) + temb.float()[:, None, None, :] + res.float().view(B, Ho, Wo, Cout)
+    assert_close(new[0].view(B, Ho, Wo, Cout), ref, dtype, f"conv {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_fused_groupnorm_conv_on_large_mean_input(L, dtype):
     """the fused front end on x = 50 + N(0, 0.1): statistics never go through E[x^2] - mean^2, so the conv of the normalised tensor
     matches torch's to the precision the stored input allows"""
