@@ -72,7 +72,11 @@ constexpr int CH_HW = CH_PW + 2;                          // halo row length (18
 // well as the halo) besides the in-place transform, and the eight MFMA waves only read fragments and issue MFMAs between barriers: an
 // MFMA wave that issues its share of the weight pieces right after the barrier queues behind the other waves' pieces in the CU's one
 // vector-memory front end for 400-600 cycles per step (profiles/r05_halo_phase_probe*.txt) before it reaches its first fragment read.
-template <typename T, int FN, int FM, int S, int HWV, bool KS = false, bool SVC = false>
+// SHARE (round 6, the K-split form): the next chunk's halo is issued AHEAD of tap 0's weight pieces and waited for before tap 1's barrier,
+// so that barrier publishes it to every wave and all sixteen transform it -- the MFMA waves one piece each behind their MFMAs of tap 1 (they
+// wait ~1500 cycles per step at the barrier), the service waves one piece each at taps 1 and 2 -- instead of the eight service waves taking
+// two pieces at tap 1 and one at tap 2 in series with their 3-4 weight pieces per step (the step's critical path, tools/halo_phase_probe.py)
+template <typename T, int FN, int FM, int S, int HWV, bool KS = false, bool SVC = false, bool SHARE = false>
 __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 : 1)) void conv_halo_kernel(const GemmParams p, const int tiles_x, const int tiles_y, const int tiles_n) {
     constexpr int NSTG = HWV ? HWV : 8;                     // waves that stage the halo
     constexpr int CH_PH = 4 * FM;                           // output patch height
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
     constexpr int WQ = (WPIECES + NWS - 1) / NWS;           // ... pieces per such wave
     static_assert(!KS || HWV > 0, "the KS form runs with halo waves");
     static_assert(!SVC || HWV > 0, "service waves are the extra waves");
+    static_assert(!SHARE || (KS && SVC && HWV == 8), "sixteen waves share the transform of the K-split form");
     typedef typename Vec<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo0 = smem;
@@ -271,12 +276,15 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                         // (at most S - 2) and the next chunk's halo if it was issued inside that window (at tap 0, behind that step's weights)
                         const int ahead = min(S - 2, nsteps - 1 - step);
                         wait_vmcnt_of<(S - 2) * WQ, (S - 2) * (WQ - 1), (S - 2) * WQ + HQ, (S - 2) * WQ + HQ - 1, (S - 2) * (WQ - 1) + HQ, (S - 2) * (WQ - 1) + HQ - 1>(
-                            ahead * nW + ((tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0));
+                            ahead * nW + ((!SHARE && tap >= 1 && tap <= S - 1 && ct + 1 < cpt) ? nH : 0));
                     }
                     CH_TICK(0);
                     __builtin_amdgcn_s_barrier();                        // ... before the step that may read them; the halo buffer
                     asm volatile("" ::: "memory");                       // of chunk ct - 1 is free from (ct, tap 0) on
                     CH_TICK(1);
+                    if constexpr (SHARE) {                               // (SHARE: the halo ahead of this step's weight pieces, which have two steps of flight)
+                        if (tap == 0 && ct + 1 < cpt) stage_halo((ct + 1) & 1, ct + 1);
+                    }
                     if constexpr (SVC) {
                         if (step + S - 1 < nsteps) {
                             const int ns = step + S - 1, nct = step_ct(ns);
@@ -285,7 +293,11 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                     }
                     // (interleaving the weight pieces with the transform of the halo pieces -- one LDS-DMA, one piece, ... -- and the halo
                     // ahead of step 0's weights measured SLOWER: 96.0 vs 89.6 us per fused conv2 at 32 x 32, profiles/r05_halo_phase_probe.txt)
-                    if (ct + 1 < cpt) {
+                    if (SHARE && ct + 1 < cpt) {
+                        // of the 23 pieces the MFMA waves take 0 .. 7 at tap 1 and 12 .. 19 at tap 2; the service waves the rest, ONE per wave and
+                        // chunk: waves 0-3 pieces 8 .. 11 (their own second DMA piece) at tap 1, waves 4-6 pieces 20 .. 22 (their third) at tap 2
+                        if (gn && ((tap == 1 && sw < 4) || (tap == 2 && sw >= 4))) norm_halo_n((ct + 1) & 1, ct + 1, tap, tap + 1, std::integral_constant<int, 1>{});
+                    } else if (ct + 1 < cpt) {
                         if (tap == 0) stage_halo((ct + 1) & 1, ct + 1);
                         if constexpr (TPS == 1) {
                             // two steps of flight; behind the halo in this wave's queue: the weights issued at taps 1 and 2
@@ -328,6 +340,17 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
         wait_vmcnt_dyn(min(S - 1, nsteps) * nW);
         norm_halo(0, 0, 0, HQ);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written back before the barrier of step 0 publishes the halo
+    }
+    bool share_real = false, share_real2 = false;       // SHARE: is this lane's pixel of halo piece wave | 12 + wave inside the image (padding stays zero)?
+    if constexpr (SHARE) {
+        static_assert(!SHARE || (HPIECES == 23), "piece split of the 8 x 16 patch");
+        auto inside = [&](int piece) {
+            const int h = piece * 8 + (lane >> 3);
+            const int hy = h / CH_HW, hx = h - hy * CH_HW;
+            const int iy = ty * CH_PH + hy - 1, ix = tx * CH_PW + hx - 1;
+            return h < CH_HALO && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        };
+        share_real = inside(wave); share_real2 = inside(12 + wave);
     }
     int step = 0;
 #if CH_TIMING
@@ -388,6 +411,16 @@ __global__ __launch_bounds__(64 * (8 + HWV), HWV ? (8 + HWV) / 4 : (S == 2 ? 2 :
                 if constexpr (TPS > 1 && FM * FN >= 20) __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("" ::: "memory");
+            if constexpr (SHARE) {
+                if (gn && tap >= 1 && ct + 1 < cpt) {            // piece wave | 12 + wave of the next chunk's halo (landed and published by tap 1's barrier)
+                    HaloNorm<T> hm;
+                    hm.load(gtab, ct + 1, gch);
+                    unsigned char* const addr[1] = {halo0 + ((ct + 1) & 1) * CH_HALO_BYTES + (tap == 1 ? wave : 12 + wave) * 8 * GEMM_ROW_BYTES + lane * 16};
+                    const bool valid[1] = {true}, real[1] = {tap == 1 ? share_real : share_real2};
+                    hm.template run<1>(addr, valid, real, p.gn_silu != 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
             CH_TICK(3);
         }
     }
@@ -496,7 +529,8 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
     // g_halo_mode 6 = the kernels below (A/B, the bit-identity test)
     if (!ks && bn == 160 && (bm == 7128 || bm == 7256 || bm == 7356) && g_halo_mode == 0)
         return conv_hws_launch(p, dtype, ph, tiles_x, tiles_y, tiles_n, B, gnf ? p.Cin * 8 : 0, stream);
-#define IMH_CH6(TT, FNV, FMV, SV, HV, KSV, SVCV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV, SVCV>; static DynLdsOnce lds_once; \
+#define IMH_CH6(TT, FNV, FMV, SV, HV, KSV, SVCV) IMH_CH7(TT, FNV, FMV, SV, HV, KSV, SVCV, false)
+#define IMH_CH7(TT, FNV, FMV, SV, HV, KSV, SVCV, SHV) do { auto kern = conv_halo_kernel<TT, FNV, FMV, SV, HV, KSV, SVCV, SHV>; static DynLdsOnce lds_once; \
         lds_once.ensure((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * (8 + HV)), lds, stream, p, tiles_x, tiles_y, tiles_n); } while (0)
 #define IMH_CH5(TT, FNV, FMV, SV, HV, KSV) IMH_CH6(TT, FNV, FMV, SV, HV, KSV, KSV)
@@ -514,17 +548,17 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
         else IMH_CH6(TT, FNV, FMV, SV, 0, false, false); } while (0)
 #define IMH_CH(TT) do { \
         if (ks && ph == 16) { if (g_halo_mode == 5) IMH_CH6(TT, 5, 4, 2, 4, true, true); else IMH_CH6(TT, 5, 4, 2, 8, true, true); } \
-        else if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
+        else if (ks) { if (g_halo_mode == 8) IMH_CH5(TT, 5, 2, 3, 8, true); else IMH_CH7(TT, 5, 2, 3, 8, true, true, true); } \
         else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (S == 3) IMH_CH3(TT, 5, 2, 3); else if (S == 4) IMH_CH3(TT, 5, 2, 4); \
         else if (bn == 320) { if (ph == 8) IMH_CH3(TT, 10, 2, 2); else IMH_CH3(TT, 10, 1, 2); } \
         else { if (ph == 8) IMH_CH3(TT, 5, 2, 2); else IMH_CH3(TT, 5, 1, 2); } } while (0)
 #else
-    if (!hw4 || (g_halo_mode >= 3 && g_halo_mode != 6) || bm == 7564 || bm == 7328 || bm == 7428 || (ks && ph == 16))
+    if (!hw4 || (g_halo_mode >= 3 && g_halo_mode < 6) || bm == 7564 || bm == 7328 || bm == 7428 || (ks && ph == 16))
         return experimental_refused("this LDS-halo conv form (eight-wave / service-wave A-B modes, variants 7564 / 7328 / 7428 / 7256 x 80)");
 #define IMH_CH3(TT, FNV, FMV, SV) IMH_CH6(TT, FNV, FMV, SV, 4, false, false)
 #define IMH_CH(TT) do { \
-        if (ks) IMH_CH5(TT, 5, 2, 3, 8, true); \
+        if (ks) { if (g_halo_mode == 8) IMH_CH5(TT, 5, 2, 3, 8, true); else IMH_CH7(TT, 5, 2, 3, 8, true, true, true); } \
         else if (ph == 16) { if (S == 3) IMH_CH3(TT, 5, 4, 3); else IMH_CH3(TT, 5, 4, 2); } \
         else if (bn == 320) IMH_CH3(TT, 10, 2, 2); \
         else IMH_CH3(TT, 5, 2, 2); } while (0)
@@ -535,6 +569,7 @@ int conv_halo_launch(const GemmParams& p, int dtype, int bm, int bn, hipStream_t
 #undef IMH_CH3
 #undef IMH_CH5
 #undef IMH_CH6
+#undef IMH_CH7
     return check_launch("conv_halo_kernel");
 }
 

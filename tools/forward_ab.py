@@ -78,6 +78,7 @@ CONFIGS = collections.OrderedDict([
     ("conv64_p16ks80_w4", dict(halo=5, tuning={f"8192,640,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
     ("conv128_p16ks80", dict(tuning={f"32768,320,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640)})),
     ("res_late", dict(ws_early=0)),                   # imh_debug_set key 6 = 0: residual rows fetched after the K loop (rounds 2-4)
+    ("ks_service_transform", dict(halo=8)),           # round 6: the 8 x 16 x 80 K-split form with the eight service waves transforming the whole halo (default: all sixteen waves share it)
     ("halo_lockstep", dict(halo=6)),                  # round 6: conv_halo.hip's kernels for the 16 x 16 / 8 x 16 patch x 160 forms (default: conv_hws.hip, wave-specialised)
     ("halo_svc8", dict(halo=4)),                      # eight service waves on the 8 x 16 x 160 forms (experimental build)
     ("halo_svc8_ring3", dict(halo=4, tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
