@@ -672,7 +672,7 @@ def main():
                          "frac_at_sampled_clock": (achieved / (2500.0 * clocks["sclk_mhz"] / 2400.0)) if clocks else None,
                          "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g_by / n_g,
-                         "kernel": "imh::gemm_* (Linear + implicit-GEMM conv3x3 family: gemm_kernel, gemm_dual, gemm_ring, gemm_kg2, gemm_pq, gemm_ws, conv_halo)",
+                         "kernel": "imh::gemm_* (Linear + implicit-GEMM conv3x3 family: gemm_kernel, gemm_dual, gemm_ring, gemm_kg2, gemm_pq, gemm_ws, gemm_w16, conv_halo, conv_hws)",
                          "launches_per_step": n_g, "avg_launch_us": g_ms / n_g * 1e3,
                          "algorithmic_tflop_per_step": g_fl / 1e12,
                          "whole_forward_tflops": tot_fl / (dt / a.steps / a.denoise_steps) / 1e12},
