@@ -213,6 +213,196 @@ __global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same 256 x 320 tile on EIGHT fat waves (round 6, third structural attempt at ff.net.0; imh_debug_set key 9).  The sixteen-wave kernel above
+// and the 256 x 160 wave-specialised kernel share the 64 x 80 wave tile, and that tile is LDS-PORT-bound: per K tile the waves read 288 KB of
+// fragments (18 KB each) + 73.7 KB of LDS-DMA writes = 2826 cycles of the CU's 128 B/clk port beside 2560 cycles of MFMA (measured: ~4500 per K
+// tile).  Eight waves as 2 (M) x 4 (N) own 128 x 80 each: 26 KB of fragment reads per wave and K tile, 208 + 73.7 KB = 2200 cycles of the port.
+//   * 160 accumulator registers + the weight fragments of BOTH k steps (40) + four rotating token-fragment registers (16): 256 registers, two
+//     waves per SIMD, no producer waves -- every wave issues nine of the 72 LDS-DMA pieces of a K tile, one per 5-MFMA block.
+//   * one K tile = 16 blocks of 5 MFMAs (block = k step, 16-row token fragment); the block's token fragment was read three blocks earlier, the
+//     weight fragments of k step 1 under k step 0's blocks.  ONE barrier per K tile, at the start of block 13: by then every read of the tile
+//     has been issued (lgkmcnt(0)), this wave's pieces of tile t + 1 have landed (vmcnt(0)); behind it the tile's slot is refilled with tile
+//     t + 2 (pieces 0-2 in blocks 13-15, 3-8 in blocks 0-5 of the next tile) and the last three blocks' MFMAs run beside the first reads of
+//     tile t + 1.  No branch in the loop body: past the end the pieces re-fetch the last tile into a slot nobody reads.
+//   * same operands, swizzles, fragment maps, accumulation order and epilogue arithmetic as the kernels above: bit-identical results.
+int g_w16_form = 0;      // imh_debug_set key 9: 0 = sixteen waves of 64 x 80, 1 = eight waves of 128 x 80
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 320, TM = 128, TN = 80, FM = 8, FN = 5;
+    constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
+    constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;       // 73,728 B
+    constexpr int NB = 2 * FM, AHEAD = 3, BAR = NB - AHEAD; // blocks per K tile, token-fragment look-ahead, the block that starts with the barrier
+    constexpr int NPC = 9;                                  // LDS-DMA pieces per wave and K tile (72 / 8)
+    typedef typename Vec<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int m0, n0;
+    if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;
+    const int nkt = p.K / GEMM_BK;
+
+    // ---- staging: wave w issues pieces w + 8 k, k < 9; piece q = tile rows 8 q .. 8 q + 7, rows [0, 256) = tokens (k < 4: rows r0 + 64 k, the
+    //      swizzle has period 16), [256, 576) = weights (k >= 4: weight rows r0 + 64 (k - 4), the swizzle differs per piece).  32-bit offsets
+    //      from the two uniform bases (the launcher checks the operands stay below 4 GB).
+    const int r0 = wave * 8 + (lane >> 3);
+    const unsigned xofs = (unsigned)((m0 + r0) * p.ldx * (int)sizeof(T)) + stage_chunk_x(r0, lane) * 16;
+    const unsigned xstride = (unsigned)(64 * p.ldx * (int)sizeof(T));
+    unsigned wofs[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int row = r0 + 64 * k;
+        wofs[k] = (unsigned)((n0 + row) * p.ldw * (int)sizeof(T)) + stage_chunk_w(row, lane, FN) * 16;
+    }
+    auto piece = [&](auto K_, int slot, int kt) {          // piece K_ of this wave of K tile kt -> its slot
+        constexpr int k = decltype(K_)::value;
+        unsigned char* d = smem + slot * STAGE + (wave + 8 * k) * 1024;
+        const unsigned ko = (unsigned)kt * (GEMM_BK * (unsigned)sizeof(T));
+        if constexpr (k < 4) glds16((const unsigned char*)p.X + (size_t)(xofs + k * xstride + ko), d);
+        else glds16((const unsigned char*)p.W + (size_t)(wofs[k - 4] + ko), d);
+    };
+
+    int xoff[2], woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int xr = wm * TM + (lane & 15);
+        const int wr = wn * TN + w_frag_row(lane & 15, 0, FN);
+        xoff[kk] = tile_off(xr, kk * 4 + (lane >> 4), swz_x(xr));
+        woff[kk] = XT_BYTES + tile_off(wr, kk * 4 + (lane >> 4), swz_w(wr, FN));
+    }
+
+    // prologue: tile 0 entirely, pieces 0-2 of tile 1 (as blocks 13-15 of "tile -1" would have issued them)
+    piece(std::integral_constant<int, 0>{}, 0, 0); piece(std::integral_constant<int, 1>{}, 0, 0); piece(std::integral_constant<int, 2>{}, 0, 0);
+    piece(std::integral_constant<int, 3>{}, 0, 0); piece(std::integral_constant<int, 4>{}, 0, 0); piece(std::integral_constant<int, 5>{}, 0, 0);
+    piece(std::integral_constant<int, 6>{}, 0, 0); piece(std::integral_constant<int, 7>{}, 0, 0); piece(std::integral_constant<int, 8>{}, 0, 0);
+    {
+        const int k1 = min(1, nkt - 1);
+        piece(std::integral_constant<int, 0>{}, 1, k1); piece(std::integral_constant<int, 1>{}, 1, k1); piece(std::integral_constant<int, 2>{}, 1, k1);
+    }
+    // (mean, rstd) of the tile's 256 token rows, merged from the producer GEMM's slot partials (imh_lnstats.h) beside tile 0's flight
+    if (tid < BM) {
+        const f32x2s mr = merge_row_stats(p.ln_stats, m0 + tid, p.ln_slots, p.K, p.ln_eps);
+        *(f32x2s*)(smem + 2 * STAGE + tid * 8) = mr;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8 wf[2][FN], xr[4];
+    auto ldw = [&](auto KK, const unsigned char* st) {
+        constexpr int kk = decltype(KK)::value;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[kk][j] = *(const v8*)(st + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+    };
+    auto ldx = [&](auto BI, const unsigned char* st) {
+        constexpr int bi = decltype(BI)::value;
+        xr[bi % 4] = *(const v8*)(st + xoff[bi / FM] + (bi % FM) * 16 * GEMM_ROW_BYTES);
+    };
+    auto mmb = [&](auto BI) {
+        constexpr int bi = decltype(BI)::value;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[bi % FM][j] = mfma16(wf[bi / FM][j], xr[bi % 4], acc[bi % FM][j]);
+    };
+    const std::integral_constant<int, 0> K0{};
+    const std::integral_constant<int, 1> K1{};
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     // this wave's pieces of tile 0 have landed (and its statistics row is written)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ldw(K0, smem);
+    ldx(std::integral_constant<int, 0>{}, smem); ldx(std::integral_constant<int, 1>{}, smem); ldx(std::integral_constant<int, 2>{}, smem);
+
+    for (int t = 0; t < nkt; ++t) {
+        const unsigned char* st = smem + (t & 1) * STAGE;
+        const unsigned char* stn = smem + ((t + 1) & 1) * STAGE;
+        const int kt1 = min(t + 1, nkt - 1), kt2 = min(t + 2, nkt - 1);
+        auto block = [&](auto BI) {
+            constexpr int bi = decltype(BI)::value;
+            if constexpr (bi == 0) ldw(K1, st);
+            if constexpr (bi == BAR) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // every read of tile t has completed; this wave's pieces of tile t + 1 have landed
+                __builtin_amdgcn_s_barrier();                                    // ... everyone's
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                ldw(K0, stn);
+            }
+            if constexpr (bi + AHEAD < NB) ldx(std::integral_constant<int, bi + AHEAD>{}, st);
+            else ldx(std::integral_constant<int, bi + AHEAD - NB>{}, stn);      // (bi >= BAR: behind the barrier)
+            if constexpr (bi < NPC - 3) piece(std::integral_constant<int, bi + 3>{}, (t + 1) & 1, kt1);        // pieces 3-8 of tile t + 1
+            if constexpr (bi >= BAR) piece(std::integral_constant<int, bi - BAR>{}, t & 1, kt2);               // pieces 0-2 of tile t + 2 -> the slot just freed
+            mmb(BI);
+            // the reads and the LDS-DMA piece go into the MFMAs' shadows
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{}); block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{}); block(std::integral_constant<int, 8>{});
+        block(std::integral_constant<int, 9>{}); block(std::integral_constant<int, 10>{}); block(std::integral_constant<int, 11>{});
+        block(std::integral_constant<int, 12>{}); block(std::integral_constant<int, 13>{}); block(std::integral_constant<int, 14>{});
+        block(std::integral_constant<int, 15>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the re-fetched pieces behind the last tile have landed: the LDS may be released
+
+    // ---- epilogue (the sixteen-wave kernel's, eight row fragments per wave) ----
+    const int nb = n0 + wn * TN + (lane >> 4) * (4 * FN);
+    const float* ex = (const float*)(smem + 2 * STAGE);
+    const bool geglu = p.flags & GF_GEGLU;
+    typedef typename Pk2<T>::t pk2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                           // four row fragments at a time (the packed outputs of eight would not fit beside the accumulators)
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wm * TM + (4 * h + i) * 16 + (lane & 15);
+            mean[i] = ex[r * 2]; rstd[i] = ex[r * 2 + 1];
+        }
+        if (geglu) {
+            pk2 outp[4][FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + 4 * j), c4 = *(const f32x4*)(p.ln_c + nb + 4 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4], o[2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fma_nopk(rstd[i], fma_nopk(-mean[i], s4[e], acc[4 * h + i][j][e]), c4[e]);      // (no bias: fold_ln puts it into c_n)
+                    geglu_quads<4>(v, o);
+                    outp[i][j][0] = from_f32<T>(o[0]);
+                    outp[i][j][1] = from_f32<T>(o[1]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * TM + (4 * h + i) * 16 + (lane & 15);
+                T* y = (T*)p.Y + (size_t)m * p.ldy + (nb >> 1);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) *(pk2*)(y + 2 * j) = outp[i][j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * TM + (4 * h + i) * 16 + (lane & 15);
+                float v[4 * FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const f32x4 s4 = *(const f32x4*)(p.ln_s + nb + 4 * j), c4 = *(const f32x4*)(p.ln_c + nb + 4 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = fma_nopk(rstd[i], fma_nopk(-mean[i], s4[e], acc[4 * h + i][j][e]), c4[e]);
+                }
+                stv<T, 4 * FN>((T*)p.Y + (size_t)m * p.ldy + nb, v);
+            }
+        }
+    }
+    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+}
+
 template <typename T>
 static int launch_w16(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
@@ -220,6 +410,13 @@ static int launch_w16(const GemmParams& p, hipStream_t stream) {
     int tiles;
     xcd_partition(q, 256, 320, &tiles);
     const int smem = 2 * (256 + 320) * GEMM_ROW_BYTES + 256 * 8 + 1024;      // + the prefetch pieces' scratch KB
+    if (g_w16_form == 1 && (size_t)p.M * p.ldx * sizeof(T) < (1ull << 31) && (size_t)p.N * p.ldw * sizeof(T) < (1ull << 31)) {
+        auto kern = gemm_f8_kernel<T>;
+        static DynLdsOnce lds_once8;
+        lds_once8.ensure((const void*)kern, smem);
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, stream, q);
+        return check_launch("gemm_f8_kernel");
+    }
     auto kern = gemm_w16_kernel<T>;
     static DynLdsOnce lds_once;
     lds_once.ensure((const void*)kern, smem);

@@ -103,6 +103,7 @@ int xattn_launch(const XAttnParams& p, int dtype, hipStream_t stream);
 extern int g_attn_force_nw;
 extern int g_xattn_mode;
 extern int g_w16_pf;
+extern int g_w16_form;
 extern int g_attn_mode;
 extern int g_xcd_mode;
 extern int g_halo_mode;

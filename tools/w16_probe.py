@@ -20,8 +20,9 @@ for dtype in (torch.bfloat16, torch.float16):
         wg, s_, c_ = fold_ln(w, norm, ctx)
         st = ctx.row_stats(x)
         res = {}
-        for cfg in ((23256, 160, 1), (26256, 320, 1)):
-            a, out, *_ = ctx.gemm(x, wg, flags=flags, ln=(s_, c_, 1e-5, st), cfg=cfg, _args_only=True)
+        for cfg in ((23256, 160, 1), (26256, 320, 1), (26256, 320, 1, 'f8')):
+            ctx.lib.imh_debug_set(9, 1 if len(cfg) == 4 else 0)      # key 9: the 256 x 320 tile on eight fat waves
+            a, out, *_ = ctx.gemm(x, wg, flags=flags, ln=(s_, c_, 1e-5, st), cfg=cfg[:3], _args_only=True)
             for _ in range(3):
                 L.check(ctx.lib.imh_gemm(C.byref(a), ctx.stream()), "gemm")
             torch.cuda.synchronize()
@@ -36,8 +37,8 @@ for dtype in (torch.bfloat16, torch.float16):
                 junk.fill_(1); torch.cuda.synchronize()
                 e0.record(); L.check(ctx.lib.imh_gemm(C.byref(a), ctx.stream()), "gemm"); e1.record(); torch.cuda.synchronize()
                 cold.append(e0.elapsed_time(e1) * 1e3)
-            res[cfg[0]] = (warm, sorted(cold)[2], out.clone())
-            if TIMING and cfg[0] == 26256:
+            res['f8' if len(cfg) == 4 else cfg[0]] = (warm, sorted(cold)[2], out.clone())
+            if TIMING and cfg[0] == 26256 and len(cfg) == 3:
                 q = lambda t, f: float(t.kthvalue(max(1, int(f * t.numel())))[0])
                 dbg = torch.zeros(8 + 4 * 4096, dtype=torch.int64, device=DEV)
                 a.pf_ptr, a.pf_bytes = dbg.data_ptr(), 0xfeed
@@ -52,8 +53,11 @@ for dtype in (torch.bfloat16, torch.float16):
                     print(f"    {lab}: {d.shape[0]} tiles; entry median {q(ent, .5):.1f} / max {float(ent.max()):.1f}; prologue median {q(l0 - ent, .5):.1f}; K loop median {q(l1 - l0, .5):.1f} / max "
                           f"{float((l1 - l0).max()):.1f}; epilogue median {q(ex - l1, .5):.1f} / max {float((ex - l1).max()):.1f}; last exit {float(ex.max()):.1f} us", flush=True)
                 a.pf_ptr, a.pf_bytes = None, 0
+        ctx.lib.imh_debug_set(9, 0)
         same = torch.equal(res[23256][2], res[26256][2])
+        same8 = torch.equal(res[23256][2], res['f8'][2])
         d = (res[23256][2].float() - res[26256][2].float()).abs().max().item()
         fl = 2.0 * M * N * K
         print(f"{str(dtype)[6:]:9s} {M}x{N}x{K} flags={flags}: 256x160 {res[23256][0]:6.1f} us warm / {res[23256][1]:6.1f} cold | 256x320 sixteen waves {res[26256][0]:6.1f} us warm "
-              f"({fl / res[26256][0] / 1e6:5.0f} TF) / {res[26256][1]:6.1f} cold | bit-identical {same} (max |d| {d:.2e})", flush=True)
+              f"({fl / res[26256][0] / 1e6:5.0f} TF) / {res[26256][1]:6.1f} cold | eight fat waves {res['f8'][0]:6.1f} us warm ({fl / res['f8'][0] / 1e6:5.0f} TF) / {res['f8'][1]:6.1f} cold | "
+              f"bit-identical {same} / {same8} (max |d| {d:.2e})", flush=True)
