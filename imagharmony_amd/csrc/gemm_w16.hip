@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
 //     t + 2 (pieces 0-2 in blocks 13-15, 3-8 in blocks 0-5 of the next tile) and the last three blocks' MFMAs run beside the first reads of
 //     tile t + 1.  No branch in the loop body: past the end the pieces re-fetch the last tile into a slot nobody reads.
 //   * same operands, swizzles, fragment maps, accumulation order and epilogue arithmetic as the kernels above: bit-identical results.
-int g_w16_form = 0;      // imh_debug_set key 9: 0 = sixteen waves of 64 x 80, 1 = eight waves of 128 x 80
+int g_w16_form = 1;      // imh_debug_set key 9: 1 (default) = eight waves of 128 x 80, 0 = sixteen waves of 64 x 80 (A/B)
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 320, TM = 128, TN = 80, FM = 8, FN = 5;
@@ -241,6 +241,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+#if W16_TIMING
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     int m0, n0;
     if (!xcd_tile<BM, BN>(p, blockIdx.x, m0, n0)) return;
     const int nkt = p.K / GEMM_BK;
@@ -292,53 +295,87 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Fragment reads as inline asm with HAND-COUNTED lgkmcnt: left to hipcc, every third block waited lgkmcnt(0) -- for the read it had issued
+    // one MFMA earlier -- instead of the lgkmcnt(2) that leaves the two younger token fragments in flight.  In-order LDS returns; at the start of
+    // block b the fragment of block b (read at b - 3) must be there, the reads of blocks b - 2 and b - 1 may fly: one token fragment each, plus
+    // the five weight fragments read in block 0 (k step 1) and in block BAR (k step 0 of the next tile).
     v8 wf[2][FN], xr[4];
-    auto ldw = [&](auto KK, const unsigned char* st) {
+    const unsigned lds0 = (unsigned)(size_t)smem;           // (flat -> LDS offset: the low 32 bits)
+    auto rd16 = [&](v8& dst, unsigned addr, auto OFF) {
+        constexpr int off = decltype(OFF)::value;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+    };
+    auto ldw = [&](auto KK, unsigned sta) {                  // sta = LDS address of the stage
         constexpr int kk = decltype(KK)::value;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wf[kk][j] = *(const v8*)(st + woff[kk] + j * 4 * GEMM_ROW_BYTES);
+        const unsigned a = sta + woff[kk];
+        rd16(wf[kk][0], a, std::integral_constant<int, 0 * 4 * GEMM_ROW_BYTES>{}); rd16(wf[kk][1], a, std::integral_constant<int, 1 * 4 * GEMM_ROW_BYTES>{});
+        rd16(wf[kk][2], a, std::integral_constant<int, 2 * 4 * GEMM_ROW_BYTES>{}); rd16(wf[kk][3], a, std::integral_constant<int, 3 * 4 * GEMM_ROW_BYTES>{});
+        rd16(wf[kk][4], a, std::integral_constant<int, 4 * 4 * GEMM_ROW_BYTES>{});
     };
-    auto ldx = [&](auto BI, const unsigned char* st) {
+    auto ldx = [&](auto BI, unsigned sta) {
         constexpr int bi = decltype(BI)::value;
-        xr[bi % 4] = *(const v8*)(st + xoff[bi / FM] + (bi % FM) * 16 * GEMM_ROW_BYTES);
+        rd16(xr[bi % 4], sta + xoff[bi / FM], std::integral_constant<int, (bi % FM) * 16 * GEMM_ROW_BYTES>{});
     };
-    auto mmb = [&](auto BI) {
-        constexpr int bi = decltype(BI)::value;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[bi % FM][j] = mfma16(wf[bi / FM][j], xr[bi % 4], acc[bi % FM][j]);
+    auto mm1 = [&](auto BI, auto J) {
+        constexpr int bi = decltype(BI)::value, j = decltype(J)::value;
+        acc[bi % FM][j] = mfma16(wf[bi / FM][j], xr[bi % 4], acc[bi % FM][j]);
     };
     const std::integral_constant<int, 0> K0{};
     const std::integral_constant<int, 1> K1{};
+    const std::integral_constant<int, 0> J0{}; const std::integral_constant<int, 1> J1{}; const std::integral_constant<int, 2> J2{};
+    const std::integral_constant<int, 3> J3{}; const std::integral_constant<int, 4> J4{};
     asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     // this wave's pieces of tile 0 have landed (and its statistics row is written)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ldw(K0, smem);
-    ldx(std::integral_constant<int, 0>{}, smem); ldx(std::integral_constant<int, 1>{}, smem); ldx(std::integral_constant<int, 2>{}, smem);
+    ldw(K0, lds0);
+    ldx(std::integral_constant<int, 0>{}, lds0); ldx(std::integral_constant<int, 1>{}, lds0); ldx(std::integral_constant<int, 2>{}, lds0);
+
+    // the next launch's weights (ff.net.2) travel inside the K loop, as in the sixteen-wave kernel: one extra 1-KB piece per wave behind block 5's
+    // operand piece of every PFS-th tile, left in flight across that tile's barrier (vmcnt(1)) and retired with the next tile's pieces
+    const bool pf_loop = p.early_res == 2 && p.pf_ptr != nullptr && !W16_TIMING;
+    const unsigned pf_per = pf_loop ? ((((p.pf_bytes + gridDim.x - 1) / gridDim.x) + 1023u) & ~1023u) : 0u;
+    const unsigned pf_s0 = blockIdx.x * pf_per;
+    const int pf_n = pf_loop ? (int)((min(p.pf_bytes, pf_s0 + pf_per) > pf_s0 ? min(p.pf_bytes, pf_s0 + pf_per) - pf_s0 : 0u) >> 10) : 0;
+    const int pf_rounds = (pf_n + 7) >> 3;
+    const int PFS = pf_rounds > 0 ? max(1, (nkt - 1) / pf_rounds) : 1;
+    unsigned char* const pf_lds = smem + 2 * STAGE + 256 * 8;
+#if W16_TIMING
+    const unsigned long long ts_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int t = 0; t < nkt; ++t) {
-        const unsigned char* st = smem + (t & 1) * STAGE;
-        const unsigned char* stn = smem + ((t + 1) & 1) * STAGE;
+        const unsigned st = lds0 + (t & 1) * STAGE, stn = lds0 + ((t + 1) & 1) * STAGE;
         const int kt1 = min(t + 1, nkt - 1), kt2 = min(t + 2, nkt - 1);
+        const int pfq = (t / PFS) * 8 + wave;
+        const bool pf_now = pf_loop && t + 1 < nkt && t % PFS == 0 && pfq < pf_n;       // (wave-uniform)
         auto block = [&](auto BI) {
             constexpr int bi = decltype(BI)::value;
-            if constexpr (bi == 0) ldw(K1, st);
             if constexpr (bi == BAR) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // every read of tile t has completed; this wave's pieces of tile t + 1 have landed
+                if (pf_now) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // every read of tile t has completed; this wave's pieces of tile t + 1 have landed
                 __builtin_amdgcn_s_barrier();                                    // ... everyone's
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                ldw(K0, stn);
+            } else if constexpr (bi == 1 || bi == 2 || bi == BAR + 1 || bi == BAR + 2) {
+                asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+            mm1(BI, J0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (bi == 0) ldw(K1, st);
+            if constexpr (bi == BAR) ldw(K0, stn);
             if constexpr (bi + AHEAD < NB) ldx(std::integral_constant<int, bi + AHEAD>{}, st);
             else ldx(std::integral_constant<int, bi + AHEAD - NB>{}, stn);      // (bi >= BAR: behind the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            mm1(BI, J1);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (bi < NPC - 3) piece(std::integral_constant<int, bi + 3>{}, (t + 1) & 1, kt1);        // pieces 3-8 of tile t + 1
             if constexpr (bi >= BAR) piece(std::integral_constant<int, bi - BAR>{}, t & 1, kt2);               // pieces 0-2 of tile t + 2 -> the slot just freed
-            mmb(BI);
-            // the reads and the LDS-DMA piece go into the MFMAs' shadows
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if constexpr (bi == NPC - 3)
+                if (pf_now) glds16((const unsigned char*)p.pf_ptr + pf_s0 + (size_t)pfq * 1024 + lane * 16, pf_lds);
+            __builtin_amdgcn_sched_barrier(0);
+            mm1(BI, J2); mm1(BI, J3); mm1(BI, J4);
             __builtin_amdgcn_sched_barrier(0);
         };
         block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{});
@@ -348,7 +385,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
         block(std::integral_constant<int, 12>{}); block(std::integral_constant<int, 13>{}); block(std::integral_constant<int, 14>{});
         block(std::integral_constant<int, 15>{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the re-fetched pieces behind the last tile have landed: the LDS may be released
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the re-fetched pieces and the look-ahead reads behind the last tile have landed: LDS and fragment registers may be reused
+#if W16_TIMING
+    const unsigned long long ts_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue (the sixteen-wave kernel's, eight row fragments per wave) ----
     const int nb = n0 + wn * TN + (lane >> 4) * (4 * FN);
@@ -400,7 +440,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
             }
         }
     }
-    tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+#if W16_TIMING
+    if (tid == 0 && p.pf_ptr && p.pf_bytes == 0xfeed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)p.pf_ptr + 8 + (size_t)blockIdx.x * 4;
+        dbg[0] = ts_entry; dbg[1] = ts_loop0; dbg[2] = ts_loop1; dbg[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#else
+    if (!pf_loop) tail_prefetch(p.pf_ptr, p.pf_bytes, blockIdx.x, gridDim.x, tid, 512);
+#endif
 }
 
 template <typename T>

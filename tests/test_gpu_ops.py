@@ -714,7 +714,8 @@ def test_gemm_folded_layernorm(L, dtype, cfg, shape):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape,slots", [((256, 320, 64), 1), ((512, 640, 1280), 16), ((2048, 10240, 1280), 16), ((768, 960, 640), 8)])
 def test_gemm_sixteen_wave_256x320_tile(L, dtype, shape, slots):
-    """Round 6, csrc/gemm_w16.hip (variant 26256 x 320; tuning.json takes it for the ff.net.0 launches): row-form folded LayerNorm with
+    """Round 6, csrc/gemm_w16.hip (variant 26256 x 320; tuning.json takes it for the ff.net.0 launches; its default form since the end of
+    round 6 is eight fat waves, the sixteen-wave kernel stays as the A/B form): row-form folded LayerNorm with
     handed-over statistics, plain and + GEGLU, (a) against F.layer_norm + matmul (+ GEGLU) in fp32, (b) BIT-identical to the
     wave-specialised 256 x 160 kernel it replaces (same operands, same order of operations per output element), (c) bitwise repeatable;
     and the launch refuses what it does not implement (a bias, a residual, ragged tiles) with a status code."""
@@ -736,6 +737,12 @@ def test_gemm_sixteen_wave_256x320_tile(L, dtype, shape, slots):
         assert_close(y, want, dtype, f"sixteen-wave 256 x 320, {what} {shape}", k=8.0)
         assert torch.equal(y, ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(23256, 160, 1))), f"{what}: differs from the 256 x 160 kernel"
         assert torch.equal(y, ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))), f"{what}: not repeatable"
+        try:        # the default form is eight fat waves of 128 x 80 (gemm_f8_kernel); imh_debug_set(9, 0) = the sixteen 64 x 80 waves: the same bits
+            ctx.lib.imh_debug_set(9, 0)
+            y16 = ctx.gemm(x, wg, flags=flags, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))
+        finally:
+            ctx.lib.imh_debug_set(9, 1)
+        assert torch.equal(y, y16), f"{what}: the eight-wave and the sixteen-wave forms differ"
     b = rnd(N, dtype=dtype, seed=5)
     with pytest.raises(L.ImhError, match="26256"):
         ctx.gemm(x, wg, bias=b, flags=L.GF_LN_ROW, ln=(s, c, 1e-5, st), cfg=(26256, 320, 1))

@@ -35,6 +35,7 @@ CONFIGS = collections.OrderedDict([
     # handed to the launches before, nearest first
     ("pf_cap8", dict(pf_chunk=8 << 20, pf_cap=True)), ("pf_cap4", dict(pf_chunk=4 << 20, pf_cap=True)), ("pf_off", dict(pf_chunk=4096, pf_cap=True)),
     ("w16_pf_tail", dict(w16_pf=0)),        # round 6: ff.net.0 prefetching ff.net.2 behind its epilogue (the in-loop form is the default)
+    ("pf_everything", dict(pf_big=1 << 30, pf_big_cap=0)),        # round 5's rule: every weight rides the previous launch's tail
     ("pf_big0", dict(pf_big=14 << 20, pf_big_cap=0)), ("pf_big2", dict(pf_big=14 << 20, pf_big_cap=2 << 20)), ("pf_big4", dict(pf_big=14 << 20, pf_big_cap=4 << 20)),
     ("pf_big8", dict(pf_big=14 << 20, pf_big_cap=8 << 20)), ("pf_big13", dict(pf_big=14 << 20, pf_big_cap=13 << 20)),
     ("pf_chunk8", dict(pf_chunk=8 << 20, pf_back=4)), ("pf_chunk13", dict(pf_chunk=13 << 20, pf_back=3)), ("pf_chunk4", dict(pf_chunk=4 << 20, pf_back=7)),
@@ -79,7 +80,7 @@ CONFIGS = collections.OrderedDict([
     ("conv128_p16ks80", dict(tuning={f"32768,320,{k},1": [7256, 80, 1] for k in (2880, 5760, 8640)})),
     ("res_late", dict(ws_early=0)),                   # imh_debug_set key 6 = 0: residual rows fetched after the K loop (rounds 2-4)
     ("ks_service_transform", dict(halo=8)),           # round 6: the 8 x 16 x 80 K-split form with the eight service waves transforming the whole halo (default: all sixteen waves share it)
-    ("geglu_f8", dict(w16_form=1)),                   # round 6: the 256 x 320 ff.net.0 tile on eight fat waves (128 x 80 each)
+    ("geglu_sixteen_waves", dict(w16_form=0)),        # round 6: the 256 x 320 ff.net.0 tile on sixteen 64 x 80 waves (default: eight fat waves of 128 x 80)
     ("halo_lockstep", dict(halo=6)),                  # round 6: conv_halo.hip's kernels for the 16 x 16 / 8 x 16 patch x 160 forms (default: conv_hws.hip, wave-specialised)
     ("halo_svc8", dict(halo=4)),                      # eight service waves on the 8 x 16 x 160 forms (experimental build)
     ("halo_svc8_ring3", dict(halo=4, tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
@@ -140,7 +141,7 @@ def main():
         lib.imh_debug_set(5, int(c.get("halo", 0)))
         lib.imh_debug_set(6, int(c.get("ws_early", 1)))
         lib.imh_debug_set(7, int(c.get("w16_pf", 1)))
-        lib.imh_debug_set(9, int(c.get("w16_form", 0)))
+        lib.imh_debug_set(9, int(c.get("w16_form", 1)))
         from imagharmony_amd.ctx import Ctx as _Ctx
         _Ctx.PF_CHUNK, _Ctx.PF_CAP_ONLY, _Ctx.PF_BACK = int(c.get("pf_chunk", 0)), bool(c.get("pf_cap", False)), int(c.get("pf_back", 3))
         _Ctx.PF_BIG, _Ctx.PF_BIG_CAP = int(c.get("pf_big", _PF_DEFAULT[0])), int(c.get("pf_big_cap", _PF_DEFAULT[1]))
@@ -166,7 +167,7 @@ def main():
             lib.imh_debug_set(5, int(c.get("halo", 0)))
             lib.imh_debug_set(6, int(c.get("ws_early", 1)))
             lib.imh_debug_set(7, int(c.get("w16_pf", 1)))
-            lib.imh_debug_set(9, int(c.get("w16_form", 0)))
+            lib.imh_debug_set(9, int(c.get("w16_form", 1)))
             ms = rec.time_ops()
             res[n]["per_op"] = ms if res[n]["per_op"] is None else [min(x, y) for x, y in zip(res[n]["per_op"], ms)]
             torch.cuda.synchronize()
@@ -183,7 +184,7 @@ def main():
     lib.imh_debug_set(5, 0)
     lib.imh_debug_set(6, 1)
     lib.imh_debug_set(7, 1)
-    lib.imh_debug_set(9, 0)
+    lib.imh_debug_set(9, 1)
     out = {}
     for n in names:
         rec, c = plans[n]

@@ -21,7 +21,7 @@ for dtype in (torch.bfloat16, torch.float16):
         st = ctx.row_stats(x)
         res = {}
         for cfg in ((23256, 160, 1), (26256, 320, 1), (26256, 320, 1, 'f8')):
-            ctx.lib.imh_debug_set(9, 1 if len(cfg) == 4 else 0)      # key 9: the 256 x 320 tile on eight fat waves
+            ctx.lib.imh_debug_set(9, 1 if len(cfg) == 4 else 0)      # key 9: 1 (default) = the 256 x 320 tile on eight fat waves, 0 = sixteen
             a, out, *_ = ctx.gemm(x, wg, flags=flags, ln=(s_, c_, 1e-5, st), cfg=cfg[:3], _args_only=True)
             for _ in range(3):
                 L.check(ctx.lib.imh_gemm(C.byref(a), ctx.stream()), "gemm")
@@ -38,7 +38,7 @@ for dtype in (torch.bfloat16, torch.float16):
                 e0.record(); L.check(ctx.lib.imh_gemm(C.byref(a), ctx.stream()), "gemm"); e1.record(); torch.cuda.synchronize()
                 cold.append(e0.elapsed_time(e1) * 1e3)
             res['f8' if len(cfg) == 4 else cfg[0]] = (warm, sorted(cold)[2], out.clone())
-            if TIMING and cfg[0] == 26256 and len(cfg) == 3:
+            if TIMING and cfg[0] == 26256:
                 q = lambda t, f: float(t.kthvalue(max(1, int(f * t.numel())))[0])
                 dbg = torch.zeros(8 + 4 * 4096, dtype=torch.int64, device=DEV)
                 a.pf_ptr, a.pf_bytes = dbg.data_ptr(), 0xfeed
@@ -53,7 +53,7 @@ for dtype in (torch.bfloat16, torch.float16):
                     print(f"    {lab}: {d.shape[0]} tiles; entry median {q(ent, .5):.1f} / max {float(ent.max()):.1f}; prologue median {q(l0 - ent, .5):.1f}; K loop median {q(l1 - l0, .5):.1f} / max "
                           f"{float((l1 - l0).max()):.1f}; epilogue median {q(ex - l1, .5):.1f} / max {float((ex - l1).max()):.1f}; last exit {float(ex.max()):.1f} us", flush=True)
                 a.pf_ptr, a.pf_bytes = None, 0
-        ctx.lib.imh_debug_set(9, 0)
+        ctx.lib.imh_debug_set(9, 1)
         same = torch.equal(res[23256][2], res[26256][2])
         same8 = torch.equal(res[23256][2], res['f8'][2])
         d = (res[23256][2].float() - res[26256][2].float()).abs().max().item()
