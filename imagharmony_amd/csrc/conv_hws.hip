@@ -15,10 +15,12 @@
 //     the consumers idle 700-1300 cycles at the barrier.  The slot of step - 1 is free during ALL of step, so any wave may fill it at any
 //     time of the step: the second consumer wave of each SIMD (waves 4-7, which get the matrix pipe after waves 0-3) issues its 2 pieces
 //     of step + S - 1 right behind the barrier, the first (3 pieces) behind its own MFMAs; each waits for its own pieces of step + 1.
-//   * this wave tile is LDS-bound: 8 waves x 18 | 14 fragment reads (1 KB, 8 cycles of the CU's 128 B/clk port) per step = 1152 | 896
-//     cycles beside 1280 | 640 of MFMA.  Four FAT consumers (8 | 4 patch rows x 80 couts, one per SIMD, 236 registers, token fragments
-//     rotating through four registers) read 832 | 576 but lost 25 % of the matrix pipe to the instructions between their MFMAs and could
-//     not take the weight ring: 81.8 vs 67.1 us per fused 128^2 launch -- not kept.
+//   * with the producers off the critical path the step is bound by the consumers (their second wave per SIMD arrives last): 18 | 14
+//     fragment reads per 40 | 20 MFMAs per wave, and a wave's reads and MFMAs add up rather than overlap (profiles/
+//     r05_lds_port_microbench.csv).  Four FAT consumers (8 | 4 patch rows x 80 couts, one per SIMD, 236 registers, token fragments
+//     rotating through four registers: 13 | 9 reads per 40 | 20 MFMAs) lost 25 % of the matrix pipe to the instructions between their
+//     MFMAs and could not take the weight ring: 81.8 vs 67.1 us per fused 128^2 launch -- not kept.  (Two fat waves per SIMD is what
+//     works -- gemm_w16.hip's gemm_f8_kernel -- but needs a 256 x 320 workgroup tile.)
 // Roofline: MFMA-bound, 2 * M * Cout * 9 Cin FLOP; algorithmic bytes per launch = input + weights + output (+ residual).
 #include "imh_common.h"
 #include "imh_kernels.h"

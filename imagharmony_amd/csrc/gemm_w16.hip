@@ -215,9 +215,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_w16_kernel(const GemmParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // The same 256 x 320 tile on EIGHT fat waves (round 6, third structural attempt at ff.net.0; imh_debug_set key 9).  The sixteen-wave kernel above
-// and the 256 x 160 wave-specialised kernel share the 64 x 80 wave tile, and that tile is LDS-PORT-bound: per K tile the waves read 288 KB of
-// fragments (18 KB each) + 73.7 KB of LDS-DMA writes = 2826 cycles of the CU's 128 B/clk port beside 2560 cycles of MFMA (measured: ~4500 per K
-// tile).  Eight waves as 2 (M) x 4 (N) own 128 x 80 each: 26 KB of fragment reads per wave and K tile, 208 + 73.7 KB = 2200 cycles of the port.
+// and the 256 x 160 wave-specialised kernel share the 64 x 80 wave tile: 18 fragment reads per 40 MFMAs, and a wave's reads and MFMAs add up
+// rather than overlap (profiles/r05_lds_port_microbench.csv: reads + MFMA 521 cycles, MFMA alone 333, reads alone 216) -- both run ~4500 cycles
+// per 64-k tile of this workgroup tile for 2560 of MFMA.  Eight waves as 2 (M) x 4 (N) own 128 x 80 each: 13 reads per 40 MFMAs (208 per K tile
+// instead of 288), half the barrier arrivals, half the LDS-DMA issuers.  Measured: K loop 40.8 -> 34.8 us, launch 57.2 -> 50.8 us warm.
 //   * 160 accumulator registers + the weight fragments of BOTH k steps (40) + four rotating token-fragment registers (16): 256 registers, two
 //     waves per SIMD, no producer waves -- every wave issues nine of the 72 LDS-DMA pieces of a K tile, one per 5-MFMA block.
 //   * one K tile = 16 blocks of 5 MFMAs (block = k step, 16-row token fragment); the block's token fragment was read three blocks earlier, the
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
             if constexpr (bi == NPC - 3)
                 if (pf_now) glds16((const unsigned char*)p.pf_ptr + pf_s0 + (size_t)pfq * 1024 + lane * 16, pf_lds);
             __builtin_amdgcn_sched_barrier(0);
-            mm1(BI, J2); mm1(BI, J3); mm1(BI, J4);
+            mm1(BI, J2); mm1(BI, J3); mm1(BI, J4);      // (s_setprio(1) over these: no change, 55.0 / 56.8 vs 55.7 / 55.4 us)
             __builtin_amdgcn_sched_barrier(0);
         };
         block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{});
