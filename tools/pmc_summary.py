@@ -22,7 +22,7 @@ def main():
         wr = w.get(k, {"avg": 0.0})["avg"] * 1024
         out[k] = dict(launches=f[k]["n"], fetch_bytes_per_launch=fe, write_bytes_per_launch=wr,
                       hbm_bytes_per_launch=fe + wr, avg_us_profiled=f[k]["avg_ns"] / 1e3)
-    gemm = {k: v for k, v in out.items() if any(t in k for t in ("gemm_kernel", "gemm_kg2", "gemm_ring", "gemm_dual", "gemm_pp", "gemm_pq", "gemm_pr", "gemm_ws", "gemm_w16", "conv_halo", "conv_hws"))}
+    gemm = {k: v for k, v in out.items() if any(t in k for t in ("gemm_kernel", "gemm_kg2", "gemm_ring", "gemm_dual", "gemm_pp", "gemm_pq", "gemm_pr", "gemm_ws", "gemm_w16", "gemm_f8", "conv_halo", "conv_hws"))}
     n = sum(v["launches"] for v in gemm.values())
     fam = dict(launches=n,
                fetch_bytes_per_launch=sum(v["fetch_bytes_per_launch"] * v["launches"] for v in gemm.values()) / n,
