@@ -16,6 +16,7 @@ CASES = [  # name, M, N, K, cfg, kind: plain | res (bias + residual + LN statist
     ("to_out b2", 2048, 1280, 1280, (2464, 160, 1), "res"), ("to_out b8", 8192, 1280, 1280, (23256, 160, 1), "res"),
     ("to_out b8 64x160", 8192, 1280, 1280, (2464, 160, 1), "res"), ("to_out b8 128x160", 8192, 1280, 1280, (24128, 160, 1), "res"),
     ("to_out b8 plain", 8192, 1280, 1280, (23256, 160, 1), "plain"),
+    ("[Q|K|V] b2 (LN, plain store)", 2048, 3840, 1280, (23256, 128, 1), "qkv"), ("ff.out b2", 2048, 1280, 5120, (2464, 160, 1), "res"),
     ("ff.out b8", 8192, 1280, 5120, (23256, 160, 1), "res"), ("ff.net.0 b2", 2048, 10240, 1280, (23256, 160, 1), "geglu"),
     ("ff.net.0 b8", 8192, 10240, 1280, (23256, 160, 1), "geglu"), ("to_q-like b8 (LN)", 8192, 1280, 1280, (23256, 160, 1), "qkv"),
 ]
