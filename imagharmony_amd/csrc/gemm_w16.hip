@@ -233,7 +233,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 320, TM = 128, TN = 80, FM = 8, FN = 5;
     constexpr int XT_BYTES = BM * GEMM_ROW_BYTES;
     constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;       // 73,728 B
-    constexpr int NB = 2 * FM, AHEAD = 3, BAR = NB - AHEAD; // blocks per K tile, token-fragment look-ahead, the block that starts with the barrier
+#ifndef F8_AHEAD
+#define F8_AHEAD 3      // (2 measured the same: 54.9 / 67.5 / 193.7 vs 53.1 / 66.9 / 191.6 us on the three ff.net.0 shapes)
+#endif
+    constexpr int NB = 2 * FM, AHEAD = F8_AHEAD, BAR = NB - AHEAD; // blocks per K tile, token-fragment look-ahead, the block that starts with the barrier
     constexpr int NPC = 9;                                  // LDS-DMA pieces per wave and K tile (72 / 8)
     typedef typename Vec<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     piece(std::integral_constant<int, 6>{}, 0, 0); piece(std::integral_constant<int, 7>{}, 0, 0); piece(std::integral_constant<int, 8>{}, 0, 0);
     {
         const int k1 = min(1, nkt - 1);
-        piece(std::integral_constant<int, 0>{}, 1, k1); piece(std::integral_constant<int, 1>{}, 1, k1); piece(std::integral_constant<int, 2>{}, 1, k1);
+        piece(std::integral_constant<int, 0>{}, 1, k1); piece(std::integral_constant<int, 1>{}, 1, k1);
+        if constexpr (AHEAD >= 3) piece(std::integral_constant<int, 2>{}, 1, k1);
     }
     // (mean, rstd) of the tile's 256 token rows, merged from the producer GEMM's slot partials (imh_lnstats.h) beside tile 0's flight
     if (tid < BM) {
@@ -325,11 +329,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
     const std::integral_constant<int, 1> K1{};
     const std::integral_constant<int, 0> J0{}; const std::integral_constant<int, 1> J1{}; const std::integral_constant<int, 2> J2{};
     const std::integral_constant<int, 3> J3{}; const std::integral_constant<int, 4> J4{};
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     // this wave's pieces of tile 0 have landed (and its statistics row is written)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AHEAD) : "memory");     // this wave's pieces of tile 0 have landed (and its statistics row is written)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     ldw(K0, lds0);
-    ldx(std::integral_constant<int, 0>{}, lds0); ldx(std::integral_constant<int, 1>{}, lds0); ldx(std::integral_constant<int, 2>{}, lds0);
+    ldx(std::integral_constant<int, 0>{}, lds0); ldx(std::integral_constant<int, 1>{}, lds0);
+    if constexpr (AHEAD >= 3) ldx(std::integral_constant<int, 2>{}, lds0);
 
     // the next launch's weights (ff.net.2) travel inside the K loop, as in the sixteen-wave kernel: one extra 1-KB piece per wave behind block 5's
     // operand piece of every PFS-th tile, left in flight across that tile's barrier (vmcnt(1)) and retired with the next tile's pieces
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // every read of tile t has completed; this wave's pieces of tile t + 1 have landed
                 __builtin_amdgcn_s_barrier();                                    // ... everyone's
                 asm volatile("" ::: "memory");
-            } else if constexpr (bi == 1 || bi == 2 || bi == BAR + 1 || bi == BAR + 2) {
-                asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+            } else if constexpr ((bi >= 1 && bi < AHEAD) || (bi > BAR && bi < BAR + AHEAD)) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD - 1 + 5) : "memory");
             } else {
-                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD - 1) : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
             mm1(BI, J0);
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             mm1(BI, J1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (bi < NPC - 3) piece(std::integral_constant<int, bi + 3>{}, (t + 1) & 1, kt1);        // pieces 3-8 of tile t + 1
+            if constexpr (bi < NPC - AHEAD) piece(std::integral_constant<int, bi + AHEAD>{}, (t + 1) & 1, kt1);        // pieces 3-8 of tile t + 1
             if constexpr (bi >= BAR) piece(std::integral_constant<int, bi - BAR>{}, t & 1, kt2);               // pieces 0-2 of tile t + 2 -> the slot just freed
-            if constexpr (bi == NPC - 3)
+            if constexpr (bi == NPC - AHEAD)
                 if (pf_now) glds16((const unsigned char*)p.pf_ptr + pf_s0 + (size_t)pfq * 1024 + lane * 16, pf_lds);
             __builtin_amdgcn_sched_barrier(0);
             mm1(BI, J2); mm1(BI, J3); mm1(BI, J4);      // (s_setprio(1) over these: no change, 55.0 / 56.8 vs 55.7 / 55.4 us)
