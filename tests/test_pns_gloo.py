@@ -137,7 +137,9 @@ def _worker_n(rank, world, port, seeds, q, batch, split):
             return _fake_denoise(noise)
         r = pns.run_pns(preview, seeds, (1, 4, 8, 8), final_fn=_fused_final, batch=batch,
                         final_split_fn=_split_final if split else None, pairs=pairs)
-        q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].clone(), r["owner"], calls))
+        # (by value: a torch tensor in a multiprocessing queue travels as a file descriptor the receiver fetches from THIS process -- an
+        # EOFError in the parent whenever the worker has exited first, one run in three of the world-8 case on a loaded box)
+        q.put((rank, r["best_seed"], r["scores"].tolist(), r["latents"].clone().numpy(), r["owner"], calls))
     finally:
         dist.destroy_process_group()
 
@@ -158,6 +160,7 @@ def test_pns_wider_worlds_idle_ranks_stacking_and_cfg_split_final(world, n_seeds
         assert p.exitcode == 0
     best_idx = seeds.index(single["best_seed"])
     for rank, best, scores, lat, owner, calls in res:
+        lat = torch.from_numpy(lat)
         assert best == single["best_seed"] and owner == best_idx % world
         assert torch.allclose(torch.tensor(scores), single["scores"], atol=1e-6)
         # the split final (two ranks, halves exchanged every step) reproduces the fused one: same arithmetic on the same values
