@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(const GemmParams p) {
         const int row = r0 + 64 * k;
         wofs[k] = (unsigned)((n0 + row) * p.ldw * (int)sizeof(T)) + stage_chunk_w(row, lane, FN) * 16;
     }
+    // (issuing the five weight pieces -- cold in the forward -- ahead of the token pieces measured the same: 67.7 / 66.1 vs 67.2 / 64.6 us cold)
     auto piece = [&](auto K_, int slot, int kt) {          // piece K_ of this wave of K tile kt -> its slot
         constexpr int k = decltype(K_)::value;
         unsigned char* d = smem + slot * STAGE + (wave + 8 * k) * 1024;
