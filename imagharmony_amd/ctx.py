@@ -227,14 +227,16 @@ class Ctx:
             return 0
         return cells
 
-    def _config(self, M, N, K, conv, flags, stride=1, ln_pre=False):
+    def _config(self, M, N, K, conv, flags, stride=1, ln_pre=False, up=0):
         """tile variant of a launch: the tuning table's entry for the shape if that variant implements the launch's flags
         (folded LayerNorm in either form, V^T permutation, conv stride), else the built-in heuristic -- in ONE place"""
         key = (M, N, K, int(conv))
         # a fifth key field: 1 = the entry for launches whose LayerNorm statistics are precomputed (other variants apply);
-        # 2 = the entry for a stride-2 conv whose (M, N, K) coincides with a stride-1 conv of another resolution / batch
-        cfg = (self.tuning.get(key + (1,)) if ln_pre else self.tuning.get(key + (2,)) if conv and stride == 2 else None) \
-            or self.tuning.get(key)
+        # 2 = the entry for a stride-2 conv whose (M, N, K) coincides with a stride-1 conv of another resolution / batch;
+        # 3 = the entry for a conv with fused x2 upsampling (round 6: the 64^2 -> 128^2 upsampler of UNet batch 2 shares (M, N, K) with the
+        # 64^2 ResBlock convs of UNet batch 8, which want the LDS-halo form that fuses their GroupNorm)
+        cfg = (self.tuning.get(key + (1,)) if ln_pre else self.tuning.get(key + (2,)) if conv and stride == 2
+               else self.tuning.get(key + (3,)) if conv and up else None) or self.tuning.get(key)
         if cfg is not None and self._variant_ok(cfg[0], cfg[2], flags, conv, stride, ln_pre):
             return tuple(cfg)
         bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
@@ -414,7 +416,7 @@ class Ctx:
     def conv_fuses_gn(self, M, N, K, stride=1, up=0, cfg=None):
         """True when the conv3x3 launch of this shape runs on the LDS-halo kernel, which takes the GroupNorm (+ SiLU) of its input
         (gn=...) and a two-source channel concat (x2=...) in its halo staging"""
-        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride)
+        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride, up=up)
         if bm not in self._HALO or stride != 1 or up:
             return False
         ph = 4 if bm == 7564 else (16 if bm in (7256, 7356) else 8)
@@ -447,7 +449,7 @@ class Ctx:
             out = self.new(B, Ho, Wo, Cout)
         # (the table is keyed by (M, N, K): a stride-2 conv can share its key with a stride-1 conv of another resolution /
         # batch; the LDS-halo kernel is stride-1 only -> _config falls back to the heuristic tile for that one)
-        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride)
+        bm, bn, sp = cfg or self._config(M, N, K, 1, 0, stride=stride, up=up)
         if (gn is not None or x2 is not None) and not self.conv_fuses_gn(M, N, K, stride, up, cfg=(bm, bn, sp)):
             raise L.ImhError(f"{descr}: the fused GroupNorm front end / two-source input need the LDS-halo conv3x3 (variant {bm} x {bn}, "
                              f"stride {stride}, up {up}); apply the GroupNorm / concat as passes for this launch (Ctx.conv_fuses_gn)")

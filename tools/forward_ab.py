@@ -81,6 +81,8 @@ CONFIGS = collections.OrderedDict([
     ("res_late", dict(ws_early=0)),                   # imh_debug_set key 6 = 0: residual rows fetched after the K loop (rounds 2-4)
     ("ks_service_transform", dict(halo=8)),           # round 6: the 8 x 16 x 80 K-split form with the eight service waves transforming the whole halo (default: all sixteen waves share it)
     ("geglu_sixteen_waves", dict(w16_form=0)),        # round 6: the 256 x 320 ff.net.0 tile on sixteen 64 x 80 waves (default: eight fat waves of 128 x 80)
+    ("b8_conv64_hws", dict(tuning={"32768,640,5760,1": [7356, 160, 1]})),      # round 6, UNet batch 8: the 64^2 K = 5760 convs on conv_hws (fused norm) instead of the 256 x 320 implicit GEMM
+    ("b8_conv64_hws_7128", dict(tuning={"32768,640,5760,1": [7128, 160, 1]})),
     ("halo_lockstep", dict(halo=6)),                  # round 6: conv_halo.hip's kernels for the 16 x 16 / 8 x 16 patch x 160 forms (default: conv_hws.hip, wave-specialised)
     ("halo_svc8", dict(halo=4)),                      # eight service waves on the 8 x 16 x 160 forms (experimental build)
     ("halo_svc8_ring3", dict(halo=4, tuning={f"8192,640,{k},1": [7328, 160, 1] for k in (2880, 5760, 8640, 11520, 17280)})),
