@@ -414,7 +414,11 @@ int imh_plan_get_kind(const imh_plan* p, int index);
 
 /* tuning / debugging knobs -- key 0: retired (attention workgroups are always 4 waves; accepted and ignored);
  * key 2: XCD tile placement (0 auto, 1 legacy row-major, 2..5 force the (8,1) (4,2) (2,4) (1,8) partition);
- * keys 3 / 4: cross- / self-attention kernel selection, key 5: LDS-halo conv form (0 auto, 1 eight waves, 2 halo waves),
+ * keys 3 / 4: cross- / self-attention kernel selection (3: 10 = the wide five-head form, 1 = one head per workgroup, 0 = by shape),
+ * key 5: LDS-halo conv form (0 auto: conv_hws.hip for the 160-cout forms; 6: conv_halo.hip's lock-step kernels; 8: the K-split form
+ * with the service waves transforming the whole halo), key 6: residual rows fetched before / after the K loop, key 7: ff.net.0's prefetch
+ * of the next launch's weights inside (1) / behind (0) its K loop, key 9: the 256 x 320 ff.net.0 tile on eight (1) / sixteen (0) waves,
+ * key 1: query -- 1 if the library was built with -DIMH_EXPERIMENTAL,
  * A/B and test use only: the values are process-wide plain ints read at launch time, not meant to change while another
  * thread is launching */
 int imh_debug_set(int key, int value);
