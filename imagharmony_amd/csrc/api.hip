@@ -246,6 +246,7 @@ int imh_debug_set(int key, int value) {
     if (key == 5) { g_halo_mode = value; return IMH_OK; }
     if (key == 7) { g_w16_pf = value; return IMH_OK; }        // sixteen-wave ff.net.0 tile: 1 (default) = the next launch's weights prefetched inside the K loop, 0 = behind the epilogue
     if (key == 9) { g_w16_form = value; return IMH_OK; }      // the 256 x 320 ff.net.0 tile: 0 = sixteen waves of 64 x 80, 1 = eight waves of 128 x 80
+    if (key == 10) { g_f32_exact = value; return IMH_OK; }    // imh_f32 GEMM / conv: 1 = the exact fp32 MFMA kernel for every launch, 0 (default) = bf16 hi / lo split where the K tile fits
     if (key == 6) { g_ws_early = value; return IMH_OK; }      // 0: the residual rows of the wave-specialised launches fetched after the K loop (A/B)
     set_error("debug_set: unknown key %d", key);
     return IMH_ERR_ARG;

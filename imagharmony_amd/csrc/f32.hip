@@ -136,22 +136,175 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const F32Params p) {
     }
 }
 
+// ---- the same GEMM / conv3x3 with the fp32 operands split into bf16 hi + lo and THREE bf16 MFMAs per product block (round 6) ----
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits; x w ~= hi_x hi_w + hi_x lo_w + lo_x hi_w (the dropped lo lo term is
+// 2^-16 of the product), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- 3 x 32 cycles per 32 x 32 x 16 block where the exact fp32 MFMA
+// takes 8 x 64: the matrix-pipe time of the VAE decoder drops 5.3x and the kernel becomes bound by its loads and the hi / lo conversion.
+// Relative error of a product ~2e-5 (random sign), of the decoded image ~1e-5 against the oracle VAE (bound 1e-4; the reference's own fp32
+// conv runs in TF32 -- 10 mantissa bits -- on the hardware it was written for).  g_f32_exact (imh_debug_set key 10) = 1 selects the exact
+// kernel above for every launch; launches whose K tile does not fit (K % 32, conv Cin % 32) take it anyway.
+int g_f32_exact = 0;
+constexpr int X3_BK = 32, X3_LD = 40;             // bf16 elements per LDS row: 32 k + 8 of padding (80-B rows: the 32 lanes of a fragment read spread over the banks)
+
+__global__ __launch_bounds__(256, 3) void f32_gemm_x3_kernel(const F32Params p) {
+    typedef typename Vec<bf16_t>::v8 v8;
+    typedef typename Vec<bf16_t>::v4 v4;
+    __shared__ __attribute__((aligned(16))) bf16_t Xh[F_BM][X3_LD], Xl[F_BM][X3_LD], Wh[F_BN][X3_LD], Wl[F_BN][X3_LD];      // 4 x 10 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * F_BM, n0 = blockIdx.y * F_BN;
+    // loader: thread t fetches 16 consecutive k (64 B) of tile row t >> 1 for both operands
+    const int lr = tid >> 1, kq = (tid & 1) * 16;
+    const int m = m0 + lr, n = n0 + lr;
+    const bool xok = m < p.M, wok = n < p.N;
+    const float* wsrc = p.W + (size_t)min(n, p.N - 1) * p.ldw + kq;
+    const float* xsrc = p.X;
+    int cb = 0, coy = 0, cox = 0;
+    if (p.conv) {
+        const int hw = p.Ho * p.Wo;
+        const int mm = min(m, p.M - 1);
+        cb = mm / hw;
+        const int rem = mm - cb * hw;
+        coy = rem / p.Wo;
+        cox = rem - coy * p.Wo;
+    } else {
+        xsrc = p.X + (size_t)min(m, p.M - 1) * p.ldx + kq;
+    }
+    const int Hv = p.H << p.up, Wv = p.Wd << p.up;
+    auto load = [&](int kt, f32x4 (&xv)[4], f32x4 (&wv)[4]) {
+        const int k0 = kt * X3_BK;
+        const float* xs = nullptr;
+        if (p.conv) {                              // a K tile lies inside one tap (Cin % 32 == 0)
+            const int tap = k0 / p.Cin;
+            const int c0 = k0 - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = coy + ky - 1, ix = cox + kx - 1;
+            if (xok && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv)
+                xs = p.X + (((size_t)cb * p.H + (iy >> p.up)) * p.Wd + (ix >> p.up)) * p.Cin + c0 + kq;
+        } else if (xok) {
+            xs = xsrc + k0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xv[e] = xs ? *(const f32x4*)(xs + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[e] = wok ? *(const f32x4*)(wsrc + k0 + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto split_store = [&](const f32x4 (&v)[4], bf16_t (*H)[X3_LD], bf16_t (*Lo)[X3_LD]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16_t hq = from_f32<bf16_t>(v[e][q]);
+                h[q] = hq;
+                l[q] = from_f32<bf16_t>(v[e][q] - to_f32(hq));
+            }
+            *(v4*)&H[lr][kq + 4 * e] = h;
+            *(v4*)&Lo[lr][kq + 4 * e] = l;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nkt = p.K / X3_BK;
+    f32x4 xv[4], wv[4];
+    load(0, xv, wv);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                  // every wave is past its reads of tile kt - 1
+        split_store(xv, Xh, Xl);
+        split_store(wv, Wh, Wl);
+        __syncthreads();
+        if (kt + 1 < nkt) load(kt + 1, xv, wv);           // in flight under this tile's 24 MFMAs
+#pragma unroll
+        for (int kk = 0; kk < X3_BK / 16; ++kk) {
+            v8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                 // A: row lane & 31, eight k from 8 (lane >> 5)
+                ah[i] = *(const v8*)&Xh[wm * 64 + i * 32 + l31][kk * 16 + 8 * hi];
+                al[i] = *(const v8*)&Xl[wm * 64 + i * 32 + l31][kk * 16 + 8 * hi];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *(const v8*)&Wh[wn * 64 + j * 32 + l31][kk * 16 + 8 * hi];
+                bl[j] = *(const v8*)&Wl[wn * 64 + j * 32 + l31][kk * 16 + 8 * hi];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {             // the small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = n0 + wn * 64 + j * 32 + l31;
+        if (nn >= p.N) continue;
+        const float bv = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (mm >= p.M) continue;
+                float y = acc[i][j][r] + bv;
+                if (p.residual) y += p.residual[(size_t)mm * p.ldr + nn];
+                p.Y[(size_t)mm * p.ldy + nn] = y;
+            }
+    }
+}
+
 // ---- GroupNorm, fp32.  x [B, HW, C]; partial [B, nblk, G, 2] = (mean, M2) of the block's pixels x the group's channels ----
 __global__ __launch_bounds__(256) void f32_gn_stats_kernel(const F32Params p) {
     __shared__ float cm[512], cq[512];                   // per channel: mean and M2 over the block's pixels
+    __shared__ __attribute__((aligned(16))) float ls[2048], lq[2048];      // [pixel lane][channel] shifted sums (P * C <= 2048)
     const int blk = blockIdx.x, b = blockIdx.y;
     const int ppb = (p.HW + p.nblk - 1) / p.nblk;
     const int p0 = blk * ppb, p1 = min(p.HW, p0 + ppb);
     const int np = p1 - p0;
     const float* x = p.X + ((size_t)b * p.HW + p0) * p.C;
+    // round 6: thread (pixel lane pl, channel quad cq) streams pixels pl, pl + P, ... with 16-B loads, four in flight (the round's first
+    // form walked the block's pixels one 4-B load at a time per thread: 0.3 TB/s, 39 % of the fp32 decode).  Every lane shifts by the SAME
+    // pivot -- the block's first pixel -- so the lanes' (sum, sum of squares) simply add, in a fixed order.
+    const int CQ = p.C >> 2;                             // channel quads (C % 4 == 0, C <= 512: CQ <= 128)
+    const int P = 256 / CQ;                              // pixel lanes: 8 / 4 / 2 for C = 128 / 256 / 512
+    const int cqi = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+    if (pl < P) {
+        const f32x4 pv = np > 0 ? *(const f32x4*)(x + 4 * cqi) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        int i = pl;
+        for (; i + 3 * P < np; i += 4 * P) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(x + (size_t)(i + u * P) * p.C + 4 * cqi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[u][e] - pv[e]; sv[e] += d; qv[e] = __builtin_fmaf(d, d, qv[e]); }
+        }
+        for (; i < np; i += P) {
+            const f32x4 v = *(const f32x4*)(x + (size_t)i * p.C + 4 * cqi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; sv[e] += d; qv[e] = __builtin_fmaf(d, d, qv[e]); }
+        }
+        *(f32x4*)&ls[pl * p.C + 4 * cqi] = sv;
+        *(f32x4*)&lq[pl * p.C + 4 * cqi] = qv;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < p.C; c += 256) {
         const float pivot = np > 0 ? x[c] : 0.f;
         float s = 0.f, q = 0.f;
-        for (int i = 0; i < np; ++i) {
-            const float d = x[(size_t)i * p.C + c] - pivot;
-            s += d;
-            q = __builtin_fmaf(d, d, q);
-        }
+        for (int l = 0; l < P; ++l) { s += ls[l * p.C + c]; q += lq[l * p.C + c]; }      // ascending lane order
         const float inv = np > 0 ? 1.0f / (float)np : 0.f;
         cm[c] = pivot + s * inv;
         cq[c] = fmaxf(q - s * s * inv, 0.f);
@@ -257,11 +410,15 @@ int f32_launch(int op, const F32Params& p, hipStream_t stream) {
         if (!p.conv && (p.ldx & 3)) { set_error("f32 gemm: ldx must be a multiple of 4"); return IMH_ERR_SHAPE; }
         if (p.ldw & 3) { set_error("f32 gemm: ldw must be a multiple of 4"); return IMH_ERR_SHAPE; }
         dim3 grid((p.M + F_BM - 1) / F_BM, (p.N + F_BN - 1) / F_BN);
+        if (!g_f32_exact && p.K % X3_BK == 0 && (!p.conv || p.Cin % X3_BK == 0)) {
+            hipLaunchKernelGGL(f32_gemm_x3_kernel, grid, dim3(256), 0, stream, p);
+            return check_launch("f32_gemm_x3_kernel");
+        }
         hipLaunchKernelGGL(f32_gemm_kernel, grid, dim3(256), 0, stream, p);
         return check_launch("f32_gemm_kernel");
     }
     case 1:
-        if (p.C > 512 || p.C % p.groups || p.nblk <= 0) { set_error("f32 groupnorm: C <= 512, C %% groups == 0 (C=%d groups=%d)", p.C, p.groups); return IMH_ERR_SHAPE; }
+        if (p.C > 512 || p.C % 4 || p.C % p.groups || p.nblk <= 0) { set_error("f32 groupnorm: C <= 512, C %% 4 == 0, C %% groups == 0 (C=%d groups=%d)", p.C, p.groups); return IMH_ERR_SHAPE; }
         hipLaunchKernelGGL(f32_gn_stats_kernel, dim3(p.nblk, p.B), dim3(256), 0, stream, p);
         return check_launch("f32_gn_stats_kernel");
     case 2:

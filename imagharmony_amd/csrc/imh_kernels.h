@@ -104,6 +104,7 @@ extern int g_attn_force_nw;
 extern int g_xattn_mode;
 extern int g_w16_pf;
 extern int g_w16_form;
+extern int g_f32_exact;
 extern int g_attn_mode;
 extern int g_xcd_mode;
 extern int g_halo_mode;

@@ -62,17 +62,31 @@ def test_f32_ops_against_torch():
     import torch.nn.functional as F
     from imagharmony_amd.ctx import Ctx
     ctx = Ctx(DEV, torch.bfloat16)
+    # GEMM / conv in both arithmetic modes: imh_debug_set(10, 1) = exact fp32 MFMA for every launch; 0 (default) = operands split into bf16
+    # hi + lo, three bf16 MFMAs per product (16 mantissa bits per operand: ~2e-5 per product, random sign) where the K tile fits -- bounds x4
+    for exact in (1, 0):
+        ctx.lib.imh_debug_set(10, exact)
+        tol = 1.0 if exact else 4.0
+        try:
+            _f32_gemm_conv_cases(ctx, tol)
+        finally:
+            ctx.lib.imh_debug_set(10, 0)
+    _f32_rest(ctx)
+
+
+def _f32_gemm_conv_cases(ctx, tol):
+    import torch.nn.functional as F
     for (M, N, K) in [(300, 200, 64), (128, 3, 1152), (1000, 129, 16), (64, 512, 512)]:
         x, w = det_randn((M, K), 1).to(DEV), det_randn((N, K), 2).to(DEV)
         b, r = det_randn((N,), 3).to(DEV), det_randn((M, N), 4).to(DEV)
         y = ctx.f32_gemm(x, w, bias=b, residual=r)
         ref = (x.double() @ w.double().t() + b.double() + r.double())
-        assert (y.double() - ref).abs().max() < 2e-5 * K ** 0.5 * 4, (M, N, K)
+        assert (y.double() - ref).abs().max() < tol * 2e-5 * K ** 0.5 * 4, (M, N, K, tol)
     # strided weight operand (the PV GEMM reads V^T [C, B L] one batch at a time)
     vt = det_randn((32, 3 * 128), 5).to(DEV)
     pr = det_randn((128, 128), 6).to(DEV)
     y = ctx.f32_gemm(pr, vt[:, 128:256], N=32, K=128, ldw=384)
-    assert (y.double() - pr.double() @ vt[:, 128:256].double().t()).abs().max() < 1e-3
+    assert (y.double() - pr.double() @ vt[:, 128:256].double().t()).abs().max() < tol * 1e-3
     for (B, H, W, Cin, Cout, up) in [(2, 9, 7, 16, 40, 0), (1, 8, 8, 32, 3, 1), (1, 16, 12, 64, 130, 0)]:
         x = det_randn((B, Cin, H, W), 7).to(DEV)
         w = (det_randn((Cout, Cin, 3, 3), 8) * (9 * Cin) ** -0.5).to(DEV)
@@ -82,7 +96,11 @@ def test_f32_ops_against_torch():
         res = det_randn(tuple(ref.permute(0, 2, 3, 1).shape), 10).to(DEV)
         y = ctx.f32_conv3x3(x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous(), bias=b,
                             residual=res.view(-1, Cout), up=up)
-        assert (y.double() - (ref.permute(0, 2, 3, 1) + res.double())).abs().max() < 5e-5, (B, H, W, Cin, Cout, up)
+        assert (y.double() - (ref.permute(0, 2, 3, 1) + res.double())).abs().max() < tol * 5e-5, (B, H, W, Cin, Cout, up, tol)
+
+
+def _f32_rest(ctx):
+    import torch.nn.functional as F
     for (B, HW, Cc, silu, off) in [(2, 5000, 128, True, 0.0), (1, 1024, 512, False, 300.0), (3, 70, 32, True, -40.0)]:
         x = (det_randn((B, HW, Cc), 11) * 0.7 + off).to(DEV)
         g, be = (1 + 0.2 * det_randn((Cc,), 12)).to(DEV), (0.3 * det_randn((Cc,), 13)).to(DEV)
