@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void f32_gemm_x3_kernel(const F32Params p) 
         xsrc = p.X + (size_t)min(m, p.M - 1) * p.ldx + kq;
     }
     const int Hv = p.H << p.up, Wv = p.Wd << p.up;
-    auto load = [&](int kt, f32x4 (&xv)[4], f32x4 (&wv)[4]) {
+    auto load_x = [&](int kt, f32x4 (&xv)[4]) {
         const int k0 = kt * X3_BK;
         const float* xs = nullptr;
         if (p.conv) {                              // a K tile lies inside one tap (Cin % 32 == 0)
@@ -188,10 +188,12 @@ __global__ __launch_bounds__(256, 3) void f32_gemm_x3_kernel(const F32Params p) 
             xs = xsrc + k0;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            xv[e] = xs ? *(const f32x4*)(xs + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wv[e] = wok ? *(const f32x4*)(wsrc + k0 + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int e = 0; e < 4; ++e) xv[e] = xs ? *(const f32x4*)(xs + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto load_w = [&](int kt, f32x4 (&wv)[4]) {
+        const int k0 = kt * X3_BK;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[e] = wok ? *(const f32x4*)(wsrc + k0 + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto split_store = [&](const f32x4 (&v)[4], bf16_t (*H)[X3_LD], bf16_t (*Lo)[X3_LD]) {
 #pragma unroll
@@ -216,13 +218,14 @@ __global__ __launch_bounds__(256, 3) void f32_gemm_x3_kernel(const F32Params p) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nkt = p.K / X3_BK;
     f32x4 xv[4], wv[4];
-    load(0, xv, wv);
+    load_x(0, xv); load_w(0, wv);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                  // every wave is past its reads of tile kt - 1
         split_store(xv, Xh, Xl);
-        split_store(wv, Wh, Wl);
+        if (kt + 1 < nkt) load_x(kt + 1, xv);             // each operand's next tile is requested as soon as its registers are free: in flight
+        split_store(wv, Wh, Wl);                          // under the other operand's conversion, the barrier and this tile's 24 MFMAs
+        if (kt + 1 < nkt) load_w(kt + 1, wv);
         __syncthreads();
-        if (kt + 1 < nkt) load(kt + 1, xv, wv);           // in flight under this tile's 24 MFMAs
 #pragma unroll
         for (int kk = 0; kk < X3_BK / 16; ++kk) {
             v8 ah[2], al[2], bh[2], bl[2];
