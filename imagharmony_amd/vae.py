@@ -410,10 +410,19 @@ class AutoencoderKL(nn.Module):
         overlap = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
         extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
         limit = self.tile_sample_min_size - extent
-        rows = []
-        for i in range(0, z.shape[2], overlap):
-            rows.append([self._decode_tile(z[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size].contiguous(), precision)
-                         for j in range(0, z.shape[3], overlap)])
+        # every operation of the decoder is per sample, so the tiles of one shape are decoded as ONE batch (round 6: 3 x 3 tiles of a 128 x 128
+        # latent = 4 launches' worth of work instead of 9 under-filled ones; the same bits per tile as one tile at a time)
+        ii, jj = list(range(0, z.shape[2], overlap)), list(range(0, z.shape[3], overlap))
+        tiles = {(i, j): z[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size] for i in ii for j in jj}
+        groups = {}
+        for key, t in tiles.items():
+            groups.setdefault(tuple(t.shape[2:]), []).append(key)
+        dec = {}
+        for keys in groups.values():
+            out = self._decode_tile(torch.cat([tiles[k] for k in keys], 0).contiguous(), precision)
+            for k, o in zip(keys, out.split(z.shape[0], 0)):
+                dec[k] = o
+        rows = [[dec[(i, j)] for j in jj] for i in ii]
         out_rows = []
         for i, row in enumerate(rows):
             out = []
