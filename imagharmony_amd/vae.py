@@ -411,7 +411,8 @@ class AutoencoderKL(nn.Module):
         extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
         limit = self.tile_sample_min_size - extent
         # every operation of the decoder is per sample, so the tiles of one shape are decoded as ONE batch (round 6: 3 x 3 tiles of a 128 x 128
-        # latent = 4 launches' worth of work instead of 9 under-filled ones; the same bits per tile as one tile at a time)
+        # latent = 4 launches' worth of work instead of 9 under-filled ones; in the fp32 path the same bits per tile as one tile at a time, in the
+        # 16-bit path the same to rounding -- there the GEMM variant depends on M)
         ii, jj = list(range(0, z.shape[2], overlap)), list(range(0, z.shape[3], overlap))
         tiles = {(i, j): z[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size] for i in ii for j in jj}
         groups = {}

@@ -190,6 +190,27 @@ def test_vae_tiled_decode_matches_oracle_tiled():
     assert rel_rms(img.cpu(), ref) < 3e-2
     hv.enable_tiling(False)
     assert rel_rms(decode_latents(hv, lat.to(DEV)).cpu(), ref) > 1e-3      # tiling really changes the result (per-tile GroupNorm)
+    # round 6: the tiles of one shape travel through the decoder as ONE batch -- every operation is per sample, so in the fp32 path (one
+    # kernel per op whatever M) each tile's image is the same bits as that tile decoded alone; in the 16-bit path the GEMM variant is
+    # chosen by M (split-K, tile shape), so the tile agrees to rounding only
+    for mdt, prec in ((torch.bfloat16, "native"), (torch.float16, "fp32")):
+        _, hv2 = build_pair(mdt)
+        z = (det_randn((2, 4, 64, 48), 10) * 0.4).to(DEV)
+        overlap = int(hv2.tile_latent_min_size * (1 - hv2.tile_overlap_factor))
+        T = hv2.tile_latent_min_size
+        shapes = {}
+        for i in range(0, 64, overlap):
+            for j in range(0, 48, overlap):
+                shapes.setdefault(tuple(z[:, :, i:i + T, j:j + T].shape[2:]), []).append((i, j))
+        assert max(len(v) for v in shapes.values()) >= 2, "the case must batch something"
+        for keys in shapes.values():
+            both = hv2._decode_tile(torch.cat([z[:, :, i:i + T, j:j + T] for (i, j) in keys], 0).contiguous(), prec)
+            for k, (i, j) in enumerate(keys):
+                alone = hv2._decode_tile(z[:, :, i:i + T, j:j + T].contiguous(), prec)
+                if prec == "fp32":
+                    assert torch.equal(both[2 * k:2 * k + 2], alone), (mdt, prec, i, j)
+                else:
+                    assert rel_rms(both[2 * k:2 * k + 2], alone) < 1.5e-2, (mdt, prec, i, j)
 
 
 def test_pipeline_output_types_with_vae():
